@@ -1,0 +1,189 @@
+/*
+ * hpt.h -- C ABI of the MI355X-native render core for glowcoil/path-tracer (libhpt.so).
+ *
+ * The reference (Rust, /root/reference) has no FFI or plugin interface; the seam is the one BASELINE.json's
+ * north_star names: the host keeps load.rs (load_scene, load.rs:17) and the CLI (main.rs:34-41), and replaces the
+ * buffer allocation + pixel loop of main.rs:55-115 -- i.e. Scene::sample (main.rs:85 -> scene.rs:126) and everything
+ * under it -- with calls into this library, then runs save_img (main.rs:117).  Each entry point cites what it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative hpt_status; nothing unwinds across the boundary; the text
+ *    of the last error on the calling thread is hpt_last_error().  (The reference panics, exit 101, on every error.)
+ *  - plain pointers and sizes only.  The library copies every input array during the call (caller keeps ownership).
+ *  - matrices are 3x3 COLUMN-major float[9] (m[c*3+r]) like cgmath::Matrix3 (scene.rs:102-105 Transform).
+ *  - one hpt_context drives ONE GPU from one host thread (one process per GPU); multi-GPU = one context per rank,
+ *    each rendering a sample range (first_sample, spp) of every pixel, summed afterwards (RCCL; see bench.py).
+ *  - a context is not thread-safe.  All work of a context is enqueued on one HIP stream (its own, or the one
+ *    given to hpt_context_set_stream); host-pointer entry points synchronise that stream before returning,
+ *    *_device entry points do not.
+ */
+#ifndef HPT_H
+#define HPT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hpt_context hpt_context;
+typedef struct hpt_scene hpt_scene;
+
+typedef enum {
+    HPT_OK = 0,
+    HPT_ERR_INVALID = -1,   /* bad argument / malformed input (reference: panic!/expect/unwrap) */
+    HPT_ERR_DEVICE = -2,    /* HIP runtime error */
+    HPT_ERR_NOMEM = -3,
+    HPT_ERR_STATE = -4,     /* call order (e.g. render before commit) */
+    HPT_ERR_LIMIT = -5      /* size beyond a documented limit */
+} hpt_status;
+
+enum { HPT_GEOM_NONE = 0, HPT_GEOM_SPHERE = 1, HPT_GEOM_PLANE = 2, HPT_GEOM_MESH = 3 };   /* geometry.rs:11-15 (NONE: Node.object == None) */
+enum { HPT_TEX_BLANK = 0, HPT_TEX_CHECKER = 1, HPT_TEX_IMAGE = 2 };                        /* scene.rs:54-58 TextureData */
+
+/* bvh.rs:13-23 BVHNode in the pre-order Vec the host built (bvh.rs:35-146).
+ * interior: left/right = child indices, prim = -1;  leaf: left = right = -1, prim = primitive index. */
+typedef struct {
+    int32_t left, right, prim;
+    float p1[3], p2[3];
+} hpt_bvh_node;
+
+/* scene.rs:46-58 Texture */
+typedef struct {
+    int32_t kind;            /* HPT_TEX_* */
+    int32_t image;           /* id from hpt_scene_add_image for HPT_TEX_IMAGE */
+    float color[3];
+    float color1[3], color2[3];
+    float m[9], t[3];        /* texture transform */
+} hpt_texture;
+
+/* scene.rs:33-44 Material -- only the fields Scene::cast reads (specular, glossiness, absorption are dead data) */
+typedef struct {
+    hpt_texture diffuse, reflection, refraction;
+    float emission[3];
+    float reflection_glossiness, refraction_glossiness, refraction_index;
+} hpt_material;
+
+/* scene.rs:76-85 Camera exactly as load_camera (load.rs:241-268) leaves it: dir normalised, up re-orthogonalised
+ * and NOT renormalised. */
+typedef struct {
+    float pos[3], dir[3], up[3];
+    float fov;               /* vertical, degrees */
+    uint32_t img_width, img_height;
+    float focaldist, dof;
+} hpt_camera;
+
+enum {
+    HPT_RENDER_COUNTERS = 1u,      /* run the instrumented extend kernel: fills nodes_visited / tris_tested / inst_tests */
+    HPT_RENDER_TIME_KERNELS = 2u   /* bracket every kernel with HIP events on the context stream; fills seconds_* */
+};
+
+/* replaces the constants of main.rs:27-32 and the loop bounds of main.rs:67-107 */
+typedef struct {
+    int32_t adaptive;         /* 1: reference behaviour (initial_samples, doubling up to max_samples); 0: fixed spp */
+    int32_t spp;              /* fixed mode: samples per pixel rendered by THIS call */
+    int32_t first_sample;     /* fixed mode: samples first_sample+1 ..= first_sample+spp (Halton index, main.rs:72) */
+    int32_t initial_samples;  /* main.rs:31 */
+    int32_t max_samples;      /* main.rs:32 */
+    float thresholds[3];      /* main.rs:27-29 */
+    int32_t max_depth;        /* bounces after the primary hit; a hit at depth max_depth adds its emission only.
+                                 Deliberate deviation: the reference recursion is unbounded. */
+    uint32_t seed;
+    int32_t spp_per_pass;     /* samples of every pixel in flight per wavefront pass; 0 = library default */
+    uint32_t flags;           /* HPT_RENDER_* */
+} hpt_render_params;
+
+typedef struct {
+    uint64_t rays_primary, rays_bounce;      /* Scene::intersect-equivalent segments traced */
+    uint64_t nodes_visited, tris_tested, inst_tests;   /* HPT_RENDER_COUNTERS */
+    double seconds_total;                    /* host wall clock around the whole call (after final sync) */
+    double seconds_raygen, seconds_extend, seconds_shade, seconds_resolve;   /* HPT_RENDER_TIME_KERNELS (HIP events) */
+    uint32_t launches_extend, passes;
+    uint64_t samples;                        /* pixel-samples rendered */
+} hpt_render_stats;
+
+typedef struct {
+    uint64_t rays, nodes_visited, tris_tested;
+    double seconds_kernel;     /* HIP-event time of the traversal kernel alone */
+    double seconds_total;      /* incl. H2D/D2H copies for the host-pointer entry */
+} hpt_trace_stats;
+
+/* ---- misc ---- */
+const char* hpt_version(void);
+const char* hpt_last_error(void);
+int hpt_device_count(void);
+/* Counter-based generator that replaces rand::random::<f32>() (main.rs:76-77, scene.rs:161,169,407,408,425,426).
+ *   mix(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
+ *   k1 = mix(pixel + mix(seed));  k2 = mix(sample ^ 0x5bd1e995 ^ seed*0x9E3779B9)
+ *   u  = (mix(k1 ^ mix(k2 + dim*0x9E3779B9)) >> 8) * 2^-24           in [0,1)
+ * pixel = y*W+x, sample = Halton index (1-based), dim: 0,1 lens; 2+4*depth+{0 roulette,1 lobe,2 z,3 theta}. */
+float hpt_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim);
+float hpt_halton(int32_t index, int32_t base);                                   /* scene.rs:431 */
+int hpt_tonemap_rgba8(const float* rgb, uint32_t n_pixels, uint8_t* rgba);       /* scene.rs:362 color_as_u8_array */
+
+/* ---- context ---- */
+int hpt_context_create(int device, hpt_context** out);
+void hpt_context_destroy(hpt_context* ctx);
+/* use the caller's hipStream_t (e.g. torch's current stream) for all later work; NULL = back to the context's own */
+int hpt_context_set_stream(hpt_context* ctx, void* hip_stream);
+int hpt_context_synchronize(hpt_context* ctx);
+
+/* ---- scene building: what load_scene (load.rs:17) returns, handed over piece by piece ---- */
+int hpt_scene_create(hpt_context* ctx, hpt_scene** out);
+void hpt_scene_destroy(hpt_scene* scene);
+/* geometry.rs:18-27 Mesh as load_obj (load.rs:282-321) builds it: 0-based index triples (ntri x 3) for position,
+ * normal and texture vertex; uvw is nt x 3.  nodes/nnodes = the BVH.nodes Vec that Mesh::build_bvh
+ * (geometry.rs:223, load.rs:310) produced on the host; the library validates it, refits tight boxes and flattens
+ * it to the device layout.  nodes == NULL: the library builds its own (binned-SAH) tree instead -- hits do not
+ * depend on the tree. */
+int hpt_scene_add_mesh(hpt_scene* scene, const float* verts, int32_t nv, const uint32_t* tri_idx,
+                       const float* normals, int32_t nn, const uint32_t* nrm_idx,
+                       const float* uvw, int32_t nt, const uint32_t* uv_idx, int32_t ntri,
+                       const hpt_bvh_node* nodes, int32_t nnodes, int32_t* mesh_id);
+/* TextureData::Image (scene.rs:56, load_img load.rs:437): RGB8, 3 bytes per pixel, row-major */
+int hpt_scene_add_image(hpt_scene* scene, const uint8_t* rgb8, int32_t width, int32_t height, int32_t* image_id);
+/* one entry of Scene.materials (scene.rs:12); objects refer to it by the returned id instead of by name */
+int hpt_scene_add_material(hpt_scene* scene, const hpt_material* material, int32_t* material_id);
+/* scene.rs:19-24 Node.  parent = -1: an element of Scene.nodes; otherwise a child of that node.  Call in the
+ * reference's own order (parents first, children in Vec order): tie-breaking follows it (scene.rs:196,251). */
+int hpt_scene_add_node(hpt_scene* scene, int32_t parent, int32_t geom, int32_t mesh_id, int32_t material_id,
+                       const float m[9], const float t[3], int32_t* node_id);
+int hpt_scene_set_background(hpt_scene* scene, const hpt_texture* tex);     /* Scene.background  (scene.rs:14) */
+int hpt_scene_set_environment(hpt_scene* scene, const hpt_texture* tex);    /* Scene.environment (scene.rs:15) */
+int hpt_scene_set_camera(hpt_scene* scene, const hpt_camera* cam);          /* Camera (scene.rs:76) */
+/* flatten + upload (replicated per GPU: every rank commits the same scene) */
+int hpt_scene_commit(hpt_scene* scene);
+
+/* ---- parity entry: Mesh::intersect (geometry.rs:132-158) over n local-space rays against one mesh ----
+ * prim = -1 on miss (t,u,v = 0); side: 1 = Side::Front, 0 = Side::Back.  Host pointers; outputs caller-allocated. */
+int hpt_trace_rays(hpt_scene* scene, int32_t mesh_id, int64_t n, const float* org3, const float* dir3,
+                   int32_t* prim, float* t, float* u, float* v, uint8_t* side, hpt_trace_stats* stats);
+/* same with DEVICE pointers (org4/dir4: n x float4, .w ignored; hit4: n x {t,u,v,prim-as-int-bits}, side in bit 31
+ * of inst word is not used here: side_out n x uint8).  Enqueues on the context stream and returns; with
+ * stats != NULL it synchronises and reports the HIP-event kernel time. count_visits = 1 runs the instrumented kernel. */
+int hpt_trace_rays_device(hpt_scene* scene, int32_t mesh_id, int64_t n, const void* org4, const void* dir4,
+                          void* hit4, void* side_out, int count_visits, hpt_trace_stats* stats);
+
+/* ---- test entry: Scene::intersect (scene.rs:190-208) over n world-space rays ----
+ * node = id from hpt_scene_add_node (-1 miss); pos/normal/uvw = the HitInfo after every from_local_space step. */
+int hpt_scene_intersect(hpt_scene* scene, int64_t n, const float* org3, const float* dir3,
+                        int32_t* node, int32_t* prim, float* t, uint8_t* side,
+                        float* pos3, float* normal3, float* uvw3);
+
+/* ---- render: main.rs:57-110 minus the tonemap ----
+ * rgb: W*H*3 floats, caller-allocated HOST memory; receives sum/num_samples per pixel (main.rs:109-110).
+ * samples_per_px (optional, W*H): the num_samples each pixel ended with. */
+int hpt_render(hpt_scene* scene, const hpt_render_params* params, float* rgb, uint32_t* samples_per_px,
+               hpt_render_stats* stats);
+/* fixed-spp only, DEVICE output: rgb_sum (W*H*3 floats, device memory) receives the per-pixel SUM over this
+ * call's sample range (no division) so that ranks can be summed (RCCL) and divided once.  Synchronises the
+ * context stream before returning only if stats != NULL. */
+int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
+                      hpt_render_stats* stats);
+/* optional per-sample radiance dump for parity tests (fixed mode): per_sample = W*H*spp*3 floats on the HOST,
+ * pixel-major then sample. */
+int hpt_render_samples(hpt_scene* scene, const hpt_render_params* params, float* per_sample);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,808 @@
+// hpt_api.cpp -- the C ABI of include/hpt.h: scene hand-over, flatten + upload, and the wavefront render driver.
+// Host code only (kernels live in hpt_kernels.hip).  Compiled with -ffp-contract=off: the camera frame and the
+// matrix inverses below are computed in the reference's f32 operation order.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/hpt.h"
+#include "hpt_bvh.h"
+#include "hpt_device.h"
+#include "hpt_launch.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(HPT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr) do { int rc_ = (expr); if (rc_ != HPT_OK) return rc_; } while (0)
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ------------------------------------------------------------------------------------------------ device buffers
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t need) {   // grow-only workspace
+        if (need <= bytes && p) return HPT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (need == 0) need = 16;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) { p = nullptr; return fail(HPT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); }
+        bytes = need;
+        return HPT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+template <typename T>
+static int upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) {
+    CHK(b.ensure(v.size() * sizeof(T)));
+    if (!v.empty()) HIPCHK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return HPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ context / scene
+struct hpt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int num_cus = 256;
+    int max_blocks = 2048;
+    std::vector<hipEvent_t> events;   // pool for HPT_RENDER_TIME_KERNELS
+};
+
+struct HostMesh {
+    std::vector<float> verts, normals, uvw;
+    std::vector<uint32_t> tri, ntri, ttri;
+    int32_t n_tri = 0;
+    HostTree tree;
+};
+struct HostNode { int32_t parent, geom, mesh, material; float m[9], t[3]; std::vector<int32_t> children; };
+struct HostImage { std::vector<uint8_t> px; int32_t w, h; };
+
+struct hpt_scene {
+    hpt_context* ctx = nullptr;
+    std::vector<HostMesh> meshes;
+    std::vector<HostNode> nodes;
+    std::vector<int32_t> top;
+    std::vector<hpt_material> materials;
+    std::vector<HostImage> images;
+    hpt_texture background, environment;
+    hpt_camera camera;
+    bool have_camera = false, committed = false;
+    // device side
+    DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_xinv, d_xfwd, d_materials, d_images, d_pool;
+    std::vector<DMesh> h_meshes;
+    DScene ds;
+    int stack_entries = 1;
+    // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
+    DevBuf w_q[2][3], w_hit, w_hit_inst, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
+    // trace workspace
+    DevBuf t_org, t_dir, t_hit, t_side, t_misc[7];
+};
+
+static void identity_tex(hpt_texture& t) {   // load.rs:30-34
+    std::memset(&t, 0, sizeof t);
+    t.m[0] = t.m[4] = t.m[8] = 1.0f;
+}
+
+// cgmath Matrix3::invert (column-major): from_cols(c1 x c2 / det, c2 x c0 / det, c0 x c1 / det).transpose()
+static bool mat3_invert(const float* m, float* out) {
+#define A(c, r) m[(c) * 3 + (r)]
+    const float det = A(0, 0) * (A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) - A(1, 0) * (A(0, 1) * A(2, 2) - A(2, 1) * A(0, 2)) +
+                      A(2, 0) * (A(0, 1) * A(1, 2) - A(1, 1) * A(0, 2));
+    if (det == 0.0f || det != det) return false;
+    const float c0[3] = {A(0, 0), A(0, 1), A(0, 2)}, c1[3] = {A(1, 0), A(1, 1), A(1, 2)}, c2[3] = {A(2, 0), A(2, 1), A(2, 2)};
+#undef A
+    auto cross = [](const float* a, const float* b, float* r) {
+        r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    float r0[3], r1[3], r2[3];
+    cross(c1, c2, r0); cross(c2, c0, r1); cross(c0, c1, r2);
+    for (int k = 0; k < 3; ++k) { r0[k] = r0[k] / det; r1[k] = r1[k] / det; r2[k] = r2[k] / det; }
+    // rows of the result: out(c, r=0) = r0[c] ...
+    for (int c = 0; c < 3; ++c) { out[c * 3 + 0] = r0[c]; out[c * 3 + 1] = r1[c]; out[c * 3 + 2] = r2[c]; }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ misc exports
+extern "C" const char* hpt_version(void) { return "hpt 0.1 (gfx950)"; }
+extern "C" const char* hpt_last_error(void) { return g_err.c_str(); }
+extern "C" int hpt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+static inline uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+extern "C" float hpt_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
+    const uint32_t k1 = mix32(pixel + mix32(seed));
+    const uint32_t k2 = mix32(sample ^ 0x5bd1e995U ^ (seed * 0x9E3779B9U));
+    const uint32_t h = mix32(k1 ^ mix32(k2 + dim * 0x9E3779B9U));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+extern "C" float hpt_halton(int32_t index, int32_t base) {   // scene.rs:431-443
+    float r = 0.0f, f = 1.0f;
+    for (int32_t i = index; i > 0; i /= base) {
+        f /= (float)base;
+        r += f * (float)(i % base);
+    }
+    return r;
+}
+extern "C" int hpt_tonemap_rgba8(const float* rgb, uint32_t n, uint8_t* rgba) {   // scene.rs:360-367
+    if (!rgb || !rgba) return fail(HPT_ERR_INVALID, "hpt_tonemap_rgba8: null pointer");
+    const float GAMMA = 1.0f / 2.2f;
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) {
+            float v = powf(rgb[3 * (size_t)i + c], GAMMA) * 255.0f;
+            v = fminf(fmaxf(v, 0.0f), 255.0f);   // Rust max/min drop NaN -> 0
+            rgba[4 * (size_t)i + c] = (uint8_t)v;
+        }
+        rgba[4 * (size_t)i + 3] = 255;
+    }
+    return HPT_OK;
+}
+
+extern "C" int hpt_context_create(int device, hpt_context** out) {
+    if (!out) return fail(HPT_ERR_INVALID, "hpt_context_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(HPT_ERR_DEVICE, "no HIP device available (%s): the render core has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(HPT_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    hpt_context* c = new hpt_context();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->max_blocks = c->num_cus * 8;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    *out = c;
+    return HPT_OK;
+}
+extern "C" void hpt_context_destroy(hpt_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+extern "C" int hpt_context_set_stream(hpt_context* c, void* s) {
+    if (!c) return fail(HPT_ERR_INVALID, "null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return HPT_OK;
+}
+extern "C" int hpt_context_synchronize(hpt_context* c) {
+    if (!c) return fail(HPT_ERR_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HPT_OK;
+}
+
+extern "C" int hpt_scene_create(hpt_context* ctx, hpt_scene** out) {
+    if (!ctx || !out) return fail(HPT_ERR_INVALID, "hpt_scene_create: null argument");
+    hpt_scene* s = new hpt_scene();
+    s->ctx = ctx;
+    identity_tex(s->background); identity_tex(s->environment);
+    const hpt_camera cam = {{0, 0, 0}, {0, 0, -1}, {0, 1, 0}, 40.0f, 800, 600, 1.0f, 0.0f};   // scene.rs:107-120
+    s->camera = cam;
+    std::memset(&s->ds, 0, sizeof s->ds);
+    *out = s;
+    return HPT_OK;
+}
+extern "C" void hpt_scene_destroy(hpt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_xinv, &s->d_xfwd, &s->d_materials,
+                     &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
+                     &s->w_accum, &s->w_minmax, &s->w_spp, &s->w_list[0], &s->w_list[1], &s->w_listcount, &s->w_out,
+                     &s->t_org, &s->t_dir, &s->t_hit, &s->t_side};
+    for (DevBuf* b : all) b->release();
+    for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) s->w_q[a][k].release();
+    for (DevBuf& b : s->t_misc) b.release();
+    delete s;
+}
+
+extern "C" int hpt_scene_add_mesh(hpt_scene* s, const float* verts, int32_t nv, const uint32_t* tri_idx,
+                                  const float* normals, int32_t nn, const uint32_t* nrm_idx,
+                                  const float* uvw, int32_t nt, const uint32_t* uv_idx, int32_t ntri,
+                                  const hpt_bvh_node* nodes, int32_t nnodes, int32_t* mesh_id) {
+    if (!s || !verts || !tri_idx || !normals || !nrm_idx || !uvw || !uv_idx) return fail(HPT_ERR_INVALID, "hpt_scene_add_mesh: null pointer (vt and vn are mandatory, load.rs:303-304)");
+    if (nv <= 0 || nn <= 0 || nt <= 0) return fail(HPT_ERR_INVALID, "hpt_scene_add_mesh: empty vertex/normal/texture array");
+    if (ntri <= 0) return fail(HPT_ERR_INVALID, "Cannot construct empty BVH");   // bvh.rs:37
+    if (ntri > (1 << 28)) return fail(HPT_ERR_LIMIT, "hpt_scene_add_mesh: more than 2^28 triangles in one mesh");
+    for (int64_t i = 0; i < (int64_t)ntri * 3; ++i) {
+        if (tri_idx[i] >= (uint32_t)nv) return fail(HPT_ERR_INVALID, "hpt_scene_add_mesh: vertex index %u out of range at triangle %lld", tri_idx[i], (long long)(i / 3));
+        if (nrm_idx[i] >= (uint32_t)nn) return fail(HPT_ERR_INVALID, "hpt_scene_add_mesh: normal index %u out of range at triangle %lld", nrm_idx[i], (long long)(i / 3));
+        if (uv_idx[i] >= (uint32_t)nt) return fail(HPT_ERR_INVALID, "hpt_scene_add_mesh: texture index %u out of range at triangle %lld", uv_idx[i], (long long)(i / 3));
+    }
+    HostMesh m;
+    m.verts.assign(verts, verts + (size_t)nv * 3);
+    m.normals.assign(normals, normals + (size_t)nn * 3);
+    m.uvw.assign(uvw, uvw + (size_t)nt * 3);
+    m.tri.assign(tri_idx, tri_idx + (size_t)ntri * 3);
+    m.ntri.assign(nrm_idx, nrm_idx + (size_t)ntri * 3);
+    m.ttri.assign(uv_idx, uv_idx + (size_t)ntri * 3);
+    m.n_tri = ntri;
+    if (nodes) {
+        std::string err;
+        if (!tree_from_reference_nodes(nodes, nnodes, ntri, m.tree, err)) return fail(HPT_ERR_INVALID, "%s", err.c_str());
+    } else {
+        tree_build_sah(m.verts.data(), m.tri.data(), ntri, m.tree);
+    }
+    s->meshes.push_back(std::move(m));
+    s->committed = false;
+    if (mesh_id) *mesh_id = (int32_t)s->meshes.size() - 1;
+    return HPT_OK;
+}
+extern "C" int hpt_scene_add_image(hpt_scene* s, const uint8_t* rgb8, int32_t w, int32_t h, int32_t* image_id) {
+    if (!s || w < 0 || h < 0 || (!rgb8 && (int64_t)w * h > 0)) return fail(HPT_ERR_INVALID, "hpt_scene_add_image: bad argument");
+    HostImage im; im.w = w; im.h = h;
+    im.px.assign(rgb8, rgb8 + (size_t)w * (size_t)h * 3);
+    s->images.push_back(std::move(im));
+    s->committed = false;
+    if (image_id) *image_id = (int32_t)s->images.size() - 1;
+    return HPT_OK;
+}
+static int check_texture(const hpt_scene* s, const hpt_texture& t, const char* what) {
+    if (t.kind < HPT_TEX_BLANK || t.kind > HPT_TEX_IMAGE) return fail(HPT_ERR_INVALID, "%s: unknown texture kind %d", what, t.kind);
+    if (t.kind == HPT_TEX_IMAGE && (t.image < 0 || t.image >= (int32_t)s->images.size())) return fail(HPT_ERR_INVALID, "%s: image id %d does not exist", what, t.image);
+    float inv[9];
+    if (!mat3_invert(t.m, inv)) return fail(HPT_ERR_INVALID, "%s: texture transform is singular (scene.rs:279 unwrap)", what);
+    return HPT_OK;
+}
+extern "C" int hpt_scene_add_material(hpt_scene* s, const hpt_material* m, int32_t* id) {
+    if (!s || !m) return fail(HPT_ERR_INVALID, "hpt_scene_add_material: null argument");
+    CHK(check_texture(s, m->diffuse, "material.diffuse"));
+    CHK(check_texture(s, m->reflection, "material.reflection"));
+    CHK(check_texture(s, m->refraction, "material.refraction"));
+    s->materials.push_back(*m);
+    s->committed = false;
+    if (id) *id = (int32_t)s->materials.size() - 1;
+    return HPT_OK;
+}
+extern "C" int hpt_scene_add_node(hpt_scene* s, int32_t parent, int32_t geom, int32_t mesh, int32_t material,
+                                  const float m[9], const float t[3], int32_t* node_id) {
+    if (!s || !m || !t) return fail(HPT_ERR_INVALID, "hpt_scene_add_node: null argument");
+    if (parent < -1 || parent >= (int32_t)s->nodes.size()) return fail(HPT_ERR_INVALID, "hpt_scene_add_node: parent %d does not exist", parent);
+    if (geom < HPT_GEOM_NONE || geom > HPT_GEOM_MESH) return fail(HPT_ERR_INVALID, "unknown object type");   // load.rs:92
+    if (geom == HPT_GEOM_MESH && (mesh < 0 || mesh >= (int32_t)s->meshes.size())) return fail(HPT_ERR_INVALID, "hpt_scene_add_node: mesh id %d does not exist", mesh);
+    if (geom != HPT_GEOM_NONE && (material < 0 || material >= (int32_t)s->materials.size())) return fail(HPT_ERR_INVALID, "material does not exist for object");   // scene.rs:133
+    float inv[9];
+    if (!mat3_invert(m, inv)) return fail(HPT_ERR_INVALID, "hpt_scene_add_node: node transform is singular (scene.rs:279 unwrap)");
+    HostNode n;
+    n.parent = parent; n.geom = geom; n.mesh = mesh; n.material = material;
+    std::memcpy(n.m, m, sizeof n.m); std::memcpy(n.t, t, sizeof n.t);
+    s->nodes.push_back(n);
+    const int32_t id = (int32_t)s->nodes.size() - 1;
+    if (parent < 0) s->top.push_back(id); else s->nodes[parent].children.push_back(id);
+    s->committed = false;
+    if (node_id) *node_id = id;
+    return HPT_OK;
+}
+extern "C" int hpt_scene_set_background(hpt_scene* s, const hpt_texture* t) {
+    if (!s || !t) return fail(HPT_ERR_INVALID, "null argument");
+    CHK(check_texture(s, *t, "background"));
+    s->background = *t; s->committed = false;
+    return HPT_OK;
+}
+extern "C" int hpt_scene_set_environment(hpt_scene* s, const hpt_texture* t) {
+    if (!s || !t) return fail(HPT_ERR_INVALID, "null argument");
+    CHK(check_texture(s, *t, "environment"));
+    s->environment = *t; s->committed = false;
+    return HPT_OK;
+}
+extern "C" int hpt_scene_set_camera(hpt_scene* s, const hpt_camera* c) {
+    if (!s || !c) return fail(HPT_ERR_INVALID, "null argument");
+    if (c->img_width == 0 || c->img_height == 0) return fail(HPT_ERR_INVALID, "camera: zero image size");
+    if ((uint64_t)c->img_width * c->img_height > (1ull << 26)) return fail(HPT_ERR_LIMIT, "camera: more than 2^26 pixels");
+    s->camera = *c; s->have_camera = true; s->committed = false;
+    return HPT_OK;
+}
+
+static void conv_texture(const hpt_texture& t, DTexture& d) {
+    d.kind = t.kind; d.image = t.image;
+    for (int k = 0; k < 3; ++k) { d.color[k] = t.color[k]; d.color1[k] = t.color1[k]; d.color2[k] = t.color2[k]; d.t[k] = t.t[k]; }
+    float inv[9];
+    mat3_invert(t.m, inv);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) d.minv[r * 3 + c] = inv[c * 3 + r];
+}
+
+// main.rs:43-53
+static void camera_frame(const hpt_camera& c, DCamera& f) {
+    const float PI = 3.14159265358979323846f;
+    const float height = tanf((c.fov / 2.0f) * (2.0f * PI / 360.0f)) * 2.0f * c.focaldist;
+    const float width = height * (float)c.img_width / (float)c.img_height;
+    f.pixel_height = height / (float)c.img_height;
+    f.pixel_width = width / (float)c.img_width;
+    const float* d = c.dir; const float* u = c.up;
+    const float right[3] = {d[1] * u[2] - d[2] * u[1], d[2] * u[0] - d[0] * u[2], d[0] * u[1] - d[1] * u[0]};
+    for (int k = 0; k < 3; ++k) {
+        const float b = (c.pos[k] + d[k] * c.focaldist) + u[k] * (height / 2.0f);
+        f.a[k] = b - right[k] * (width / 2.0f);
+        f.right[k] = right[k]; f.up[k] = u[k]; f.pos[k] = c.pos[k];
+    }
+    f.dof = c.dof; f.w = c.img_width; f.h = c.img_height;
+}
+
+extern "C" int hpt_scene_commit(hpt_scene* s) {
+    if (!s) return fail(HPT_ERR_INVALID, "null scene");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // ---- meshes: flatten and concatenate (child refs rebased to global node / triangle indices)
+    std::vector<float> nodes, tris, trishade;
+    s->h_meshes.clear();
+    s->stack_entries = 1;
+    for (HostMesh& m : s->meshes) {
+        FlatMesh fm; std::string err;
+        if (!flatten_mesh(m.tree, m.verts.data(), m.tri.data(), m.normals.data(), m.ntri.data(), m.uvw.data(), m.ttri.data(), m.n_tri, fm, err))
+            return fail(HPT_ERR_INVALID, "%s", err.c_str());
+        const int64_t node_base = (int64_t)(nodes.size() / 16), tri_base = (int64_t)(tris.size() / 12);
+        if (node_base + fm.n_interior >= (1ll << 31) || tri_base + m.n_tri >= (1ll << 31)) return fail(HPT_ERR_LIMIT, "scene: more than 2^31 nodes/triangles");
+        auto rebase = [&](int32_t ref) -> int32_t { return ref >= 0 ? (int32_t)(ref + node_base) : ~(int32_t)((~ref) + tri_base); };
+        for (int32_t i = 0; i < fm.n_interior; ++i) {
+            int32_t l, r;
+            std::memcpy(&l, &fm.nodes[(size_t)i * 16 + 3], 4); std::memcpy(&r, &fm.nodes[(size_t)i * 16 + 7], 4);
+            l = rebase(l); r = rebase(r);
+            std::memcpy(&fm.nodes[(size_t)i * 16 + 3], &l, 4); std::memcpy(&fm.nodes[(size_t)i * 16 + 7], &r, 4);
+        }
+        DMesh dm; std::memset(&dm, 0, sizeof dm);
+        dm.root_ref = rebase(fm.root_ref); dm.tri_base = (int32_t)tri_base; dm.ntri = m.n_tri;
+        dm.stack_need = fm.max_depth + 1;
+        if (dm.stack_need > 120) return fail(HPT_ERR_LIMIT, "bvh: tree depth %d exceeds the traversal stack limit (120); pass nodes=NULL to let the library build a balanced tree", fm.max_depth);
+        for (int k = 0; k < 3; ++k) { dm.bmin[k] = fm.bmin[k]; dm.bmax[k] = fm.bmax[k]; }
+        s->stack_entries = std::max(s->stack_entries, dm.stack_need);
+        s->h_meshes.push_back(dm);
+        nodes.insert(nodes.end(), fm.nodes.begin(), fm.nodes.end());
+        tris.insert(tris.end(), fm.tris.begin(), fm.tris.end());
+        trishade.insert(trishade.end(), fm.trishade.begin(), fm.trishade.end());
+    }
+    // ---- instances in the reference's visiting order (scene.rs:193, :245-248): object first, then children
+    std::vector<DInstance> inst; std::vector<DXformInv> xinv; std::vector<DXformFwd> xfwd;
+    {
+        struct Frame { int32_t node; size_t next_child; };
+        for (int32_t topid : s->top) {
+            std::vector<Frame> stack{{topid, 0}};
+            std::vector<int32_t> chain{topid};
+            auto emit = [&](int32_t id) -> int {
+                const HostNode& n = s->nodes[id];
+                if (n.geom == HPT_GEOM_NONE) return HPT_OK;
+                DInstance di; std::memset(&di, 0, sizeof di);
+                di.geom = n.geom; di.mesh = n.mesh; di.material = n.material; di.node_id = id;
+                di.xf_first = (int32_t)xinv.size(); di.xf_count = (int32_t)chain.size();
+                for (int32_t cid : chain) {
+                    const HostNode& cn = s->nodes[cid];
+                    float inv[9];
+                    if (!mat3_invert(cn.m, inv)) return fail(HPT_ERR_INVALID, "node transform is singular");
+                    DXformInv xi; DXformFwd xf;
+                    float* ir[3] = {xi.r0, xi.r1, xi.r2}; float* mr[3] = {xf.m0, xf.m1, xf.m2}; float* nr[3] = {xf.n0, xf.n1, xf.n2};
+                    for (int r = 0; r < 3; ++r) {
+                        for (int c = 0; c < 3; ++c) { ir[r][c] = inv[c * 3 + r]; mr[r][c] = cn.m[c * 3 + r]; nr[r][c] = inv[r * 3 + c]; }
+                        ir[r][3] = cn.t[r]; mr[r][3] = cn.t[r]; nr[r][3] = 0.0f;
+                    }
+                    xinv.push_back(xi); xfwd.push_back(xf);
+                }
+                inst.push_back(di);
+                return HPT_OK;
+            };
+            CHK(emit(topid));
+            while (!stack.empty()) {
+                Frame& f = stack.back();
+                const HostNode& n = s->nodes[f.node];
+                if (f.next_child < n.children.size()) {
+                    const int32_t c = n.children[f.next_child++];
+                    chain.push_back(c);
+                    CHK(emit(c));
+                    stack.push_back({c, 0});
+                } else { stack.pop_back(); chain.pop_back(); }
+            }
+        }
+    }
+    if (inst.size() >= 0x7fffffffu) return fail(HPT_ERR_LIMIT, "too many instances");
+    // ---- materials, images
+    std::vector<DMaterial> mats(s->materials.size());
+    for (size_t i = 0; i < mats.size(); ++i) {
+        const hpt_material& m = s->materials[i];
+        conv_texture(m.diffuse, mats[i].diffuse); conv_texture(m.reflection, mats[i].reflection); conv_texture(m.refraction, mats[i].refraction);
+        for (int k = 0; k < 3; ++k) mats[i].emission[k] = m.emission[k];
+        mats[i].refl_gloss = m.reflection_glossiness; mats[i].refr_gloss = m.refraction_glossiness; mats[i].ior = m.refraction_index;
+    }
+    std::vector<DImage> imgs(s->images.size()); std::vector<uint8_t> pool;
+    for (size_t i = 0; i < imgs.size(); ++i) {
+        imgs[i].offset = pool.size(); imgs[i].w = s->images[i].w; imgs[i].h = s->images[i].h;
+        pool.insert(pool.end(), s->images[i].px.begin(), s->images[i].px.end());
+        while (pool.size() % 16) pool.push_back(0);
+    }
+    CHK(upload(s->d_nodes, nodes, st)); CHK(upload(s->d_tris, tris, st)); CHK(upload(s->d_trishade, trishade, st));
+    CHK(upload(s->d_meshes, s->h_meshes, st)); CHK(upload(s->d_instances, inst, st));
+    CHK(upload(s->d_xinv, xinv, st)); CHK(upload(s->d_xfwd, xfwd, st));
+    CHK(upload(s->d_materials, mats, st)); CHK(upload(s->d_images, imgs, st)); CHK(upload(s->d_pool, pool, st));
+    HIPCHK(hipStreamSynchronize(st));   // the staging vectors die at scope end
+    DScene& d = s->ds;
+    d.nodes = s->d_nodes.as<float4>(); d.tris = s->d_tris.as<float4>(); d.trishade = s->d_trishade.as<float4>();
+    d.meshes = s->d_meshes.as<DMesh>(); d.instances = s->d_instances.as<DInstance>();
+    d.xinv = s->d_xinv.as<DXformInv>(); d.xfwd = s->d_xfwd.as<DXformFwd>();
+    d.materials = s->d_materials.as<DMaterial>(); d.images = s->d_images.as<DImage>(); d.image_pool = s->d_pool.as<uint8_t>();
+    d.n_instances = (int32_t)inst.size(); d.n_meshes = (int32_t)s->h_meshes.size();
+    conv_texture(s->background, d.background); conv_texture(s->environment, d.environment);
+    camera_frame(s->camera, d.cam);
+    s->committed = true;
+    return HPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ trace entries
+static int need_committed(hpt_scene* s) {
+    if (!s) return fail(HPT_ERR_INVALID, "null scene");
+    if (!s->committed) return fail(HPT_ERR_STATE, "scene not committed: call hpt_scene_commit first");
+    return HPT_OK;
+}
+
+extern "C" int hpt_trace_rays_device(hpt_scene* s, int32_t mesh_id, int64_t n, const void* org4, const void* dir4,
+                                     void* hit4, void* side_out, int count_visits, hpt_trace_stats* stats) {
+    CHK(need_committed(s));
+    if (mesh_id < 0 || mesh_id >= (int32_t)s->h_meshes.size()) return fail(HPT_ERR_INVALID, "hpt_trace_rays: mesh id %d does not exist", mesh_id);
+    if (n < 0) return fail(HPT_ERR_INVALID, "hpt_trace_rays: negative ray count");
+    if (n > 0 && (!org4 || !dir4 || !hit4 || !side_out)) return fail(HPT_ERR_INVALID, "hpt_trace_rays: null pointer");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return HPT_OK;
+    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
+    unsigned long long* d_stat = s->w_stat.as<unsigned long long>();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (stats) {
+        HIPCHK(hipMemsetAsync(d_stat, 0, 8 * sizeof(unsigned long long), st));
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    hptk_trace_rays(st, ctx->max_blocks, s->ds, s->h_meshes[mesh_id], n, (const float4*)org4, (const float4*)dir4, (float4*)hit4, (uint8_t*)side_out,
+                    count_visits != 0, d_stat);
+    HIPCHK(hipGetLastError());
+    if (stats) {
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        unsigned long long h[8];
+        HIPCHK(hipMemcpy(h, d_stat, sizeof h, hipMemcpyDeviceToHost));
+        stats->rays = (uint64_t)n; stats->nodes_visited = h[1]; stats->tris_tested = h[2];
+        stats->seconds_kernel = ms * 1e-3; stats->seconds_total = ms * 1e-3;
+    }
+    return HPT_OK;
+}
+
+static void pack4(const float* src3, int64_t n, std::vector<float>& dst) {
+    dst.resize((size_t)n * 4);
+    for (int64_t i = 0; i < n; ++i) { dst[4 * i] = src3[3 * i]; dst[4 * i + 1] = src3[3 * i + 1]; dst[4 * i + 2] = src3[3 * i + 2]; dst[4 * i + 3] = 0.0f; }
+}
+
+extern "C" int hpt_trace_rays(hpt_scene* s, int32_t mesh_id, int64_t n, const float* org3, const float* dir3,
+                              int32_t* prim, float* t, float* u, float* v, uint8_t* side, hpt_trace_stats* stats) {
+    CHK(need_committed(s));
+    if (n < 0) return fail(HPT_ERR_INVALID, "hpt_trace_rays: negative ray count");
+    if (n > 0 && (!org3 || !dir3 || !prim || !t || !u || !v || !side)) return fail(HPT_ERR_INVALID, "hpt_trace_rays: null pointer");
+    if (mesh_id < 0 || mesh_id >= (int32_t)s->h_meshes.size()) return fail(HPT_ERR_INVALID, "hpt_trace_rays: mesh id %d does not exist", mesh_id);
+    const double t0 = now_s();
+    hpt_trace_stats total; std::memset(&total, 0, sizeof total);
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t CH = 1 << 22;
+    std::vector<float> o4, d4, h4; std::vector<uint8_t> sd;
+    for (int64_t off = 0; off < n; off += CH) {
+        const int64_t m = std::min(CH, n - off);
+        pack4(org3 + 3 * off, m, o4); pack4(dir3 + 3 * off, m, d4);
+        CHK(s->t_org.ensure((size_t)m * 16)); CHK(s->t_dir.ensure((size_t)m * 16)); CHK(s->t_hit.ensure((size_t)m * 16)); CHK(s->t_side.ensure((size_t)m));
+        HIPCHK(hipMemcpyAsync(s->t_org.p, o4.data(), (size_t)m * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(s->t_dir.p, d4.data(), (size_t)m * 16, hipMemcpyHostToDevice, ctx->stream));
+        hpt_trace_stats cs;
+        CHK(hpt_trace_rays_device(s, mesh_id, m, s->t_org.p, s->t_dir.p, s->t_hit.p, s->t_side.p, stats ? 1 : 0, &cs));
+        h4.resize((size_t)m * 4); sd.resize((size_t)m);
+        HIPCHK(hipMemcpy(h4.data(), s->t_hit.p, (size_t)m * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(sd.data(), s->t_side.p, (size_t)m, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < m; ++i) {
+            int32_t p; std::memcpy(&p, &h4[4 * i + 3], 4);
+            prim[off + i] = p; t[off + i] = h4[4 * i]; u[off + i] = h4[4 * i + 1]; v[off + i] = h4[4 * i + 2]; side[off + i] = sd[i];
+        }
+        total.rays += cs.rays; total.nodes_visited += cs.nodes_visited; total.tris_tested += cs.tris_tested; total.seconds_kernel += cs.seconds_kernel;
+    }
+    total.seconds_total = now_s() - t0;
+    if (stats) *stats = total;
+    return HPT_OK;
+}
+
+extern "C" int hpt_scene_intersect(hpt_scene* s, int64_t n, const float* org3, const float* dir3,
+                                   int32_t* node, int32_t* prim, float* t, uint8_t* side, float* pos3, float* normal3, float* uvw3) {
+    CHK(need_committed(s));
+    if (n < 0) return fail(HPT_ERR_INVALID, "hpt_scene_intersect: negative ray count");
+    if (n == 0) return HPT_OK;
+    if (!org3 || !dir3) return fail(HPT_ERR_INVALID, "hpt_scene_intersect: null pointer");
+    if (n > (1ll << 26)) return fail(HPT_ERR_LIMIT, "hpt_scene_intersect: at most 2^26 rays per call");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<float> o4, d4;
+    pack4(org3, n, o4); pack4(dir3, n, d4);
+    const size_t N = (size_t)n;
+    CHK(s->t_org.ensure(N * 16)); CHK(s->t_dir.ensure(N * 16));
+    const size_t sizes[7] = {N * 4, N * 4, N * 4, N, N * 16, N * 16, N * 16};
+    for (int k = 0; k < 7; ++k) CHK(s->t_misc[k].ensure(sizes[k]));
+    HIPCHK(hipMemcpyAsync(s->t_org.p, o4.data(), N * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->t_dir.p, d4.data(), N * 16, hipMemcpyHostToDevice, st));
+    hptk_scene_intersect(st, ctx->max_blocks, s->stack_entries, s->ds, n, s->t_org.as<float4>(), s->t_dir.as<float4>(), s->t_misc[0].as<int>(),
+                         s->t_misc[1].as<int>(), s->t_misc[2].as<float>(), s->t_misc[3].as<uint8_t>(), s->t_misc[4].as<float4>(),
+                         s->t_misc[5].as<float4>(), s->t_misc[6].as<float4>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if (node) HIPCHK(hipMemcpy(node, s->t_misc[0].p, N * 4, hipMemcpyDeviceToHost));
+    if (prim) HIPCHK(hipMemcpy(prim, s->t_misc[1].p, N * 4, hipMemcpyDeviceToHost));
+    if (t) HIPCHK(hipMemcpy(t, s->t_misc[2].p, N * 4, hipMemcpyDeviceToHost));
+    if (side) HIPCHK(hipMemcpy(side, s->t_misc[3].p, N, hipMemcpyDeviceToHost));
+    std::vector<float> tmp(N * 4);
+    float* outs[3] = {pos3, normal3, uvw3};
+    for (int k = 0; k < 3; ++k) {
+        if (!outs[k]) continue;
+        HIPCHK(hipMemcpy(tmp.data(), s->t_misc[4 + k].p, N * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; ++i) { outs[k][3 * i] = tmp[4 * i]; outs[k][3 * i + 1] = tmp[4 * i + 1]; outs[k][3 * i + 2] = tmp[4 * i + 2]; }
+    }
+    return HPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ render driver
+struct EventLog {   // HPT_RENDER_TIME_KERNELS: (kind, start, stop) triples from the context's event pool
+    hpt_context* ctx; bool on; size_t used = 0;
+    struct Rec { int kind; size_t a, b; };
+    std::vector<Rec> recs;
+    int begin(int kind, hipStream_t st) {
+        if (!on) return HPT_OK;
+        while (ctx->events.size() < used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->events.push_back(e); }
+        HIPCHK(hipEventRecord(ctx->events[used], st));
+        recs.push_back({kind, used, used + 1});
+        return HPT_OK;
+    }
+    int end(hipStream_t st) {
+        if (!on) return HPT_OK;
+        HIPCHK(hipEventRecord(ctx->events[used + 1], st));
+        used += 2;
+        return HPT_OK;
+    }
+    int collect(double out[4], uint32_t* n_extend) {
+        for (int k = 0; k < 4; ++k) out[k] = 0.0;
+        for (const Rec& r : recs) {
+            float ms = 0.0f;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->events[r.a], ctx->events[r.b]));
+            out[r.kind] += ms * 1e-3;
+            if (r.kind == 1 && n_extend) (*n_extend)++;
+        }
+        return HPT_OK;
+    }
+};
+
+static int default_spp_per_pass(uint64_t npix, int want) {
+    if (want > 0) return want;
+    const uint64_t target_paths = 8ull << 20;   // ~8M paths in flight per pass
+    uint64_t s = target_paths / std::max<uint64_t>(npix, 1);
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+// one wavefront pass: raygen -> [extend -> shade]* -> resolve, all asynchronous on the context stream
+static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks) {
+    hpt_context* ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemsetAsync(ps.counts, 0, (HPT_MAX_DEPTH_LIMIT + 2) * sizeof(uint32_t), st));
+    CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps); CHK(ev.end(st));
+    const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
+    const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
+    for (int depth = 0; depth <= ps.max_depth; ++depth) {
+        CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->stack_entries, s->ds, ps, depth, counters); CHK(ev.end(st));
+        CHK(ev.begin(2, st)); hptk_shade(st, blocks, s->ds, ps, depth); CHK(ev.end(st));
+    }
+    CHK(ev.begin(3, st)); hptk_resolve(st, ctx->max_blocks, ps, accum, minmax); CHK(ev.end(st));
+    hptk_finish_pass(st, ps);
+    HIPCHK(hipGetLastError());
+    return HPT_OK;
+}
+
+static int ensure_pass_workspace(hpt_scene* s, uint64_t max_paths, DPass& ps) {
+    if (max_paths >= (1ull << 31)) return fail(HPT_ERR_LIMIT, "render: more than 2^31 paths per pass; lower spp_per_pass");
+    for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(s->w_q[a][k].ensure(max_paths * 16));
+    CHK(s->w_hit.ensure(max_paths * 16)); CHK(s->w_hit_inst.ensure(max_paths * 4)); CHK(s->w_radiance.ensure(max_paths * 16));
+    CHK(s->w_counts.ensure((HPT_MAX_DEPTH_LIMIT + 2) * sizeof(uint32_t)));
+    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
+    for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = s->w_q[a][0].as<float4>(); ps.q[a].ray_d = s->w_q[a][1].as<float4>(); ps.q[a].thr = s->w_q[a][2].as<float4>(); }
+    ps.hit = s->w_hit.as<float4>(); ps.hit_inst = s->w_hit_inst.as<uint32_t>(); ps.radiance = s->w_radiance.as<float4>();
+    ps.counts = s->w_counts.as<uint32_t>(); ps.stat = s->w_stat.as<unsigned long long>();
+    return HPT_OK;
+}
+
+static int check_params(hpt_scene* s, const hpt_render_params* p) {
+    CHK(need_committed(s));
+    if (!p) return fail(HPT_ERR_INVALID, "null render params");
+    if (!s->have_camera) return fail(HPT_ERR_STATE, "no camera set");
+    if (p->max_depth < 0 || p->max_depth > HPT_MAX_DEPTH_LIMIT) return fail(HPT_ERR_LIMIT, "max_depth must be in 0..%d", HPT_MAX_DEPTH_LIMIT);
+    if (p->adaptive) {
+        if (p->initial_samples <= 0 || p->max_samples < p->initial_samples) return fail(HPT_ERR_INVALID, "adaptive: need 0 < initial_samples <= max_samples");
+        if (p->max_samples > (1 << 20)) return fail(HPT_ERR_LIMIT, "adaptive: max_samples above 2^20");
+    } else {
+        if (p->spp <= 0 || p->first_sample < 0) return fail(HPT_ERR_INVALID, "need spp > 0 and first_sample >= 0");
+        if ((int64_t)p->spp + p->first_sample > (1 << 24)) return fail(HPT_ERR_LIMIT, "sample index above 2^24");
+    }
+    if (p->spp_per_pass < 0) return fail(HPT_ERR_INVALID, "spp_per_pass must be >= 0");
+    return HPT_OK;
+}
+
+// Fixed-spp render of samples first_sample+1 ..= first_sample+spp into accum (device, W*H*3, ADDED in sample order).
+static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, float* per_sample_host, hpt_render_stats* stats, EventLog& ev) {
+    hpt_context* ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    const int S = std::min(default_spp_per_pass(npix, p->spp_per_pass), p->spp);
+    DPass ps; std::memset(&ps, 0, sizeof ps);
+    CHK(ensure_pass_workspace(s, npix * (uint64_t)S, ps));
+    std::vector<float> hal((size_t)p->spp * 2);
+    for (int k = 0; k < p->spp; ++k) { hal[2 * k] = hpt_halton(p->first_sample + k + 1, 2); hal[2 * k + 1] = hpt_halton(p->first_sample + k + 1, 3); }
+    CHK(upload(s->w_halton, hal, st));
+    HIPCHK(hipStreamSynchronize(st));   // `hal` is pageable host memory
+    std::vector<float> rad;
+    uint32_t passes = 0;
+    for (int done = 0; done < p->spp; done += S) {
+        const int cur = std::min(S, p->spp - done);
+        ps.halton = s->w_halton.as<float2>() + done;
+        ps.pixel_list = nullptr; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
+        ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
+        CHK(run_pass(s, ps, accum, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->max_blocks));
+        ++passes;
+        if (per_sample_host) {
+            rad.resize((size_t)npix * cur * 4);
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpy(rad.data(), ps.radiance, rad.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (uint64_t px = 0; px < npix; ++px)
+                for (int k = 0; k < cur; ++k)
+                    for (int c = 0; c < 3; ++c) per_sample_host[(px * (uint64_t)p->spp + (uint64_t)(done + k)) * 3 + c] = rad[(px * (uint64_t)cur + (uint64_t)k) * 4 + c];
+        }
+    }
+    if (stats) { stats->passes += passes; stats->samples += npix * (uint64_t)p->spp; }
+    return HPT_OK;
+}
+
+static int finish_stats(hpt_scene* s, hpt_render_stats* stats, EventLog& ev, double t0) {
+    if (!stats) return HPT_OK;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    unsigned long long h[8];
+    HIPCHK(hipMemcpy(h, s->w_stat.p, sizeof h, hipMemcpyDeviceToHost));
+    stats->rays_primary = h[4]; stats->rays_bounce = h[0] - h[4];
+    stats->nodes_visited = h[1]; stats->tris_tested = h[2]; stats->inst_tests = h[3];
+    double k[4];
+    CHK(ev.collect(k, &stats->launches_extend));
+    stats->seconds_raygen = k[0]; stats->seconds_extend = k[1]; stats->seconds_shade = k[2]; stats->seconds_resolve = k[3];
+    stats->seconds_total = now_s() - t0;
+    return HPT_OK;
+}
+
+extern "C" int hpt_render_device(hpt_scene* s, const hpt_render_params* p, float* rgb_sum_device, hpt_render_stats* stats) {
+    CHK(check_params(s, p));
+    if (p->adaptive) return fail(HPT_ERR_INVALID, "hpt_render_device: fixed-spp only (adaptive sampling couples a pixel's samples; use hpt_render)");
+    if (!rgb_sum_device) return fail(HPT_ERR_INVALID, "hpt_render_device: null output");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const double t0 = now_s();
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(rgb_sum_device, 0, npix * 3 * sizeof(float), ctx->stream));
+    EventLog ev{ctx, stats && (p->flags & HPT_RENDER_TIME_KERNELS)};
+    CHK(render_fixed(s, p, rgb_sum_device, nullptr, stats, ev));
+    return finish_stats(s, stats, ev, t0);
+}
+
+extern "C" int hpt_render_samples(hpt_scene* s, const hpt_render_params* p, float* per_sample) {
+    CHK(check_params(s, p));
+    if (p->adaptive || !per_sample) return fail(HPT_ERR_INVALID, "hpt_render_samples: fixed-spp only, non-null output");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    CHK(s->w_accum.ensure(npix * 3 * sizeof(float)));
+    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(s->w_accum.p, 0, npix * 3 * sizeof(float), ctx->stream));
+    EventLog ev{ctx, false};
+    CHK(render_fixed(s, p, s->w_accum.as<float>(), per_sample, nullptr, ev));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return HPT_OK;
+}
+
+extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, uint32_t* samples_per_px, hpt_render_stats* stats) {
+    CHK(check_params(s, p));
+    if (!rgb) return fail(HPT_ERR_INVALID, "hpt_render: null output");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const double t0 = now_s();
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    CHK(s->w_accum.ensure(npix * 3 * sizeof(float))); CHK(s->w_out.ensure(npix * 3 * sizeof(float)));
+    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(s->w_accum.p, 0, npix * 3 * sizeof(float), st));
+    float* accum = s->w_accum.as<float>();
+    EventLog ev{ctx, stats && (p->flags & HPT_RENDER_TIME_KERNELS)};
+    if (!p->adaptive) {
+        CHK(render_fixed(s, p, accum, nullptr, stats, ev));
+        hptk_divide(st, ctx->max_blocks, accum, nullptr, s->w_out.as<float>(), (uint32_t)npix, (float)p->spp);
+        if (samples_per_px) for (uint64_t i = 0; i < npix; ++i) samples_per_px[i] = (uint32_t)p->spp;
+    } else {
+        // main.rs:67-107 in wavefront form: rounds of samples (have, num_samples] over the still-active pixels
+        CHK(s->w_minmax.ensure(npix * 6 * sizeof(float))); CHK(s->w_spp.ensure(npix * sizeof(uint32_t)));
+        CHK(s->w_list[0].ensure(npix * sizeof(uint32_t))); CHK(s->w_list[1].ensure(npix * sizeof(uint32_t)));
+        CHK(s->w_listcount.ensure(sizeof(uint32_t)));
+        // min = +inf, max = 0 (main.rs:90-92)
+        {
+            std::vector<float> init(npix * 6);
+            for (uint64_t i = 0; i < npix; ++i) { for (int c = 0; c < 3; ++c) { init[6 * i + c] = INFINITY; init[6 * i + 3 + c] = 0.0f; } }
+            HIPCHK(hipMemcpyAsync(s->w_minmax.p, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        hptk_fill_u32(st, ctx->max_blocks, s->w_spp.as<uint32_t>(), npix, (uint32_t)p->initial_samples);
+        const int max_round = p->max_samples;
+        std::vector<float> hal((size_t)max_round * 2);
+        for (int k = 0; k < max_round; ++k) { hal[2 * k] = hpt_halton(k + 1, 2); hal[2 * k + 1] = hpt_halton(k + 1, 3); }
+        CHK(upload(s->w_halton, hal, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int have = 0, num_samples = p->initial_samples, cur_list = -1;   // -1: all pixels
+        uint32_t n_active = (uint32_t)npix;
+        DPass ps; std::memset(&ps, 0, sizeof ps);
+        while (n_active > 0) {
+            const int round = num_samples - have;
+            uint64_t S = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)round, (8ull << 20) / n_active));
+            if (p->spp_per_pass > 0) S = std::min<uint64_t>((uint64_t)p->spp_per_pass, (uint64_t)round);
+            CHK(ensure_pass_workspace(s, (uint64_t)n_active * S, ps));
+            for (int done = 0; done < round; done += (int)S) {
+                const int cur = std::min<int>((int)S, round - done);
+                ps.halton = s->w_halton.as<float2>() + have + done;
+                ps.pixel_list = cur_list < 0 ? nullptr : s->w_list[cur_list].as<uint32_t>();
+                ps.n_slots = n_active; ps.S = (uint32_t)cur; ps.first_sample = (uint32_t)(have + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
+                CHK(run_pass(s, ps, accum, s->w_minmax.as<float>(), (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->max_blocks));
+                if (stats) { stats->passes++; stats->samples += (uint64_t)n_active * cur; }
+            }
+            have = num_samples;
+            if (num_samples >= p->max_samples) break;   // main.rs:101 first clause
+            const int next = cur_list < 0 ? 0 : 1 - cur_list;
+            HIPCHK(hipMemsetAsync(s->w_listcount.p, 0, sizeof(uint32_t), st));
+            hptk_adaptive_select(st, ctx->max_blocks, cur_list < 0 ? nullptr : s->w_list[cur_list].as<uint32_t>(), n_active, s->w_minmax.as<float>(),
+                                 p->thresholds, s->w_list[next].as<uint32_t>(), s->w_listcount.as<uint32_t>(), s->w_spp.as<uint32_t>(), (uint32_t)(num_samples * 2));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpy(&n_active, s->w_listcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            cur_list = next;
+            num_samples *= 2;
+        }
+        hptk_divide(st, ctx->max_blocks, accum, s->w_spp.as<uint32_t>(), s->w_out.as<float>(), (uint32_t)npix, 0.0f);
+        HIPCHK(hipStreamSynchronize(st));
+        if (samples_per_px) HIPCHK(hipMemcpy(samples_per_px, s->w_spp.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(rgb, s->w_out.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (stats) return finish_stats(s, stats, ev, t0);
+    return HPT_OK;
+}

@@ -1,0 +1,189 @@
+// hpt_bvh.cpp -- see hpt_bvh.h.  Host only; no recursion (reference trees can be O(n) deep).
+#include "hpt_bvh.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace {
+struct Box {
+    float mn[3], mx[3];
+    void reset() { for (int k = 0; k < 3; ++k) { mn[k] = std::numeric_limits<float>::infinity(); mx[k] = -std::numeric_limits<float>::infinity(); } }
+    void grow(const float* p) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); } }
+    void grow(const Box& b) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], b.mn[k]); mx[k] = std::max(mx[k], b.mx[k]); } }
+    float half_area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+Box tri_box(const float* verts, const uint32_t* t) {   // geometry.rs:231-233
+    Box b; b.reset();
+    b.grow(verts + 3 * (size_t)t[0]); b.grow(verts + 3 * (size_t)t[1]); b.grow(verts + 3 * (size_t)t[2]);
+    return b;
+}
+}  // namespace
+
+bool tree_from_reference_nodes(const hpt_bvh_node* nodes, int32_t nnodes, int32_t ntri, HostTree& out, std::string& err) {
+    if (ntri <= 0) { err = "Cannot construct empty BVH"; return false; }   // bvh.rs:37
+    if (nnodes != 2 * ntri - 1) { err = "bvh: node count must be 2*ntri-1 (one primitive per leaf)"; return false; }
+    out.left.resize(nnodes); out.right.resize(nnodes); out.prim.resize(nnodes); out.root = 0;
+    std::vector<uint8_t> seen_prim((size_t)ntri, 0), visited((size_t)nnodes, 0);
+    for (int32_t i = 0; i < nnodes; ++i) {
+        const hpt_bvh_node& n = nodes[i];
+        if (n.prim >= 0) {
+            if (n.prim >= ntri) { err = "bvh: leaf primitive index out of range"; return false; }
+            if (seen_prim[n.prim]) { err = "bvh: primitive referenced by two leaves"; return false; }
+            seen_prim[n.prim] = 1;
+            out.left[i] = out.right[i] = -1; out.prim[i] = n.prim;
+        } else {
+            // pre-order layout (bvh.rs:111-136): children come after their parent => the structure is acyclic
+            if (n.left <= i || n.left >= nnodes || n.right <= i || n.right >= nnodes || n.left == n.right) { err = "bvh: child index out of order/range"; return false; }
+            out.left[i] = n.left; out.right[i] = n.right; out.prim[i] = -1;
+        }
+    }
+    // every node must be reachable exactly once from the root
+    std::vector<int32_t> stack{0};
+    int64_t reached = 0;
+    while (!stack.empty()) {
+        int32_t i = stack.back(); stack.pop_back();
+        if (visited[i]) { err = "bvh: node has two parents"; return false; }
+        visited[i] = 1; ++reached;
+        if (out.prim[i] < 0) { stack.push_back(out.left[i]); stack.push_back(out.right[i]); }
+    }
+    if (reached != nnodes) { err = "bvh: unreachable nodes"; return false; }
+    return true;
+}
+
+void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, HostTree& out) {
+    const int NB = 16;
+    std::vector<Box> boxes((size_t)ntri);
+    std::vector<float> cent((size_t)ntri * 3);
+    for (int32_t i = 0; i < ntri; ++i) {
+        boxes[i] = tri_box(verts, tri_idx + 3 * (size_t)i);
+        for (int k = 0; k < 3; ++k) cent[3 * (size_t)i + k] = 0.5f * (boxes[i].mn[k] + boxes[i].mx[k]);
+    }
+    std::vector<int32_t> ids((size_t)ntri);
+    for (int32_t i = 0; i < ntri; ++i) ids[i] = i;
+    out.left.clear(); out.right.clear(); out.prim.clear();
+    out.left.reserve(2 * (size_t)ntri); out.right.reserve(2 * (size_t)ntri); out.prim.reserve(2 * (size_t)ntri);
+    struct Job { int32_t node, lo, hi; };
+    std::vector<Job> jobs;
+    auto new_node = [&]() { out.left.push_back(-1); out.right.push_back(-1); out.prim.push_back(-1); return (int32_t)out.left.size() - 1; };
+    out.root = new_node();
+    jobs.push_back({out.root, 0, ntri});
+    while (!jobs.empty()) {
+        Job j = jobs.back(); jobs.pop_back();
+        const int32_t n = j.hi - j.lo;
+        if (n == 1) { out.prim[j.node] = ids[j.lo]; continue; }
+        Box cb; cb.reset();
+        for (int32_t i = j.lo; i < j.hi; ++i) cb.grow(&cent[3 * (size_t)ids[i]]);
+        int axis = 0;
+        float ext[3] = {cb.mx[0] - cb.mn[0], cb.mx[1] - cb.mn[1], cb.mx[2] - cb.mn[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        int32_t mid = j.lo + n / 2;
+        if (ext[axis] > 0.0f) {
+            int best_axis = -1, best_split = -1; float best_cost = std::numeric_limits<float>::infinity();
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!(ext[ax] > 0.0f)) continue;
+                if (n > 4096 && ax != axis) continue;   // large ranges: longest axis only
+                Box bb[NB]; int32_t cnt[NB];
+                for (int b = 0; b < NB; ++b) { bb[b].reset(); cnt[b] = 0; }
+                const float scale = (float)NB / ext[ax];
+                for (int32_t i = j.lo; i < j.hi; ++i) {
+                    int b = (int)((cent[3 * (size_t)ids[i] + ax] - cb.mn[ax]) * scale);
+                    b = std::min(std::max(b, 0), NB - 1);
+                    bb[b].grow(boxes[ids[i]]); cnt[b]++;
+                }
+                float right_area[NB]; int32_t right_cnt[NB];
+                Box acc; acc.reset(); int32_t c = 0;
+                for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); c += cnt[b]; right_area[b] = c ? acc.half_area() : 0.0f; right_cnt[b] = c; }
+                acc.reset(); c = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    acc.grow(bb[b]); c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const float scale = (float)NB / ext[best_axis];
+                const float mnv = cb.mn[best_axis];
+                auto it = std::partition(ids.begin() + j.lo, ids.begin() + j.hi, [&](int32_t id) {
+                    int b = (int)((cent[3 * (size_t)id + best_axis] - mnv) * scale);
+                    b = std::min(std::max(b, 0), NB - 1);
+                    return b <= best_split;
+                });
+                int32_t m = (int32_t)(it - ids.begin());
+                if (m > j.lo && m < j.hi) mid = m;
+            }
+        }
+        const int32_t l = new_node(), r = new_node();
+        out.left[j.node] = l; out.right[j.node] = r;
+        jobs.push_back({r, mid, j.hi});
+        jobs.push_back({l, j.lo, mid});
+    }
+}
+
+bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_idx, const float* normals, const uint32_t* nrm_idx,
+                  const float* uvw, const uint32_t* uv_idx, int32_t ntri, FlatMesh& out, std::string& err) {
+    const int32_t nn = (int32_t)tree.left.size();
+    // post-order (children before parent) by reversing a pre-order walk
+    std::vector<int32_t> order; order.reserve(nn);
+    {
+        std::vector<int32_t> st{tree.root};
+        while (!st.empty()) {
+            int32_t i = st.back(); st.pop_back();
+            order.push_back(i);
+            if (tree.prim[i] < 0) { st.push_back(tree.left[i]); st.push_back(tree.right[i]); }
+        }
+    }
+    if ((int32_t)order.size() != nn) { err = "bvh: tree does not cover all nodes"; return false; }
+    std::vector<Box> box((size_t)nn);
+    for (int32_t k = nn - 1; k >= 0; --k) {
+        const int32_t i = order[k];
+        if (tree.prim[i] >= 0) box[i] = tri_box(verts, tri_idx + 3 * (size_t)tree.prim[i]);   // tight leaf box (bvh.rs:50-53)
+        else { box[i] = box[tree.left[i]]; box[i].grow(box[tree.right[i]]); }                 // tight refit (drops quirk 2)
+    }
+    // breadth-first numbering of interior nodes + depth
+    std::vector<int32_t> bfs_index((size_t)nn, -1), depth((size_t)nn, 0), queue;
+    out.n_interior = 0; out.max_depth = 0;
+    if (tree.prim[tree.root] < 0) { queue.push_back(tree.root); depth[tree.root] = 1; }
+    for (size_t h = 0; h < queue.size(); ++h) {
+        const int32_t i = queue[h];
+        bfs_index[i] = out.n_interior++;
+        out.max_depth = std::max(out.max_depth, depth[i]);
+        for (int32_t c : {tree.left[i], tree.right[i]})
+            if (tree.prim[c] < 0) { depth[c] = depth[i] + 1; queue.push_back(c); }
+    }
+    auto ref_of = [&](int32_t i) -> int32_t { return tree.prim[i] >= 0 ? ~tree.prim[i] : bfs_index[i]; };
+    out.root_ref = ref_of(tree.root);
+    out.nodes.assign((size_t)out.n_interior * 16, 0.0f);
+    for (int32_t i : queue) {
+        float* q = &out.nodes[(size_t)bfs_index[i] * 16];
+        const Box& L = box[tree.left[i]]; const Box& R = box[tree.right[i]];
+        const int32_t lr = ref_of(tree.left[i]), rr = ref_of(tree.right[i]);
+        q[0] = L.mn[0]; q[1] = L.mn[1]; q[2] = L.mn[2]; std::memcpy(&q[3], &lr, 4);
+        q[4] = L.mx[0]; q[5] = L.mx[1]; q[6] = L.mx[2]; std::memcpy(&q[7], &rr, 4);
+        q[8] = R.mn[0]; q[9] = R.mn[1]; q[10] = R.mn[2];
+        q[12] = R.mx[0]; q[13] = R.mx[1]; q[14] = R.mx[2];
+    }
+    for (int k = 0; k < 3; ++k) { out.bmin[k] = box[tree.root].mn[k]; out.bmax[k] = box[tree.root].mx[k]; }
+    out.tris.assign((size_t)ntri * 12, 0.0f);
+    out.trishade.assign((size_t)ntri * 28, 0.0f);
+    for (int32_t f = 0; f < ntri; ++f) {
+        const float* a = verts + 3 * (size_t)tri_idx[3 * (size_t)f];
+        const float* b = verts + 3 * (size_t)tri_idx[3 * (size_t)f + 1];
+        const float* c = verts + 3 * (size_t)tri_idx[3 * (size_t)f + 2];
+        float* t = &out.tris[(size_t)f * 12];
+        for (int k = 0; k < 3; ++k) { t[k] = a[k]; t[4 + k] = b[k] - a[k]; t[8 + k] = c[k] - a[k]; }   // geometry.rs:189-190
+        float* s = &out.trishade[(size_t)f * 28];
+        for (int k = 0; k < 3; ++k) { s[k] = a[k]; s[3 + k] = b[k]; s[6 + k] = c[k]; }
+        for (int v = 0; v < 3; ++v) {
+            const float* n = normals + 3 * (size_t)nrm_idx[3 * (size_t)f + v];
+            const float* u = uvw + 3 * (size_t)uv_idx[3 * (size_t)f + v];
+            for (int k = 0; k < 3; ++k) { s[9 + 3 * v + k] = n[k]; s[18 + 3 * v + k] = u[k]; }
+        }
+    }
+    return true;
+}

@@ -1,0 +1,30 @@
+// hpt_bvh.h -- host side of the BVH hand-over: validate the reference-built tree (bvh.rs:35-146 output), or build
+// a binned-SAH tree when the host gives none, then flatten either to the Node64 / Tri48 / TriShade device layout.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/hpt.h"
+
+struct HostTree {           // binary tree over primitives, one primitive per leaf (bvh.rs:49-55)
+    std::vector<int32_t> left, right, prim;   // interior: left/right >= 0, prim = -1; leaf: prim >= 0
+    int32_t root = 0;
+};
+
+struct FlatMesh {
+    std::vector<float> nodes;      // n_interior * 16 floats (Node64)
+    std::vector<float> tris;       // ntri * 12 floats (Tri48)
+    std::vector<float> trishade;   // ntri * 28 floats (TriShade)
+    int32_t root_ref = -1;         // LOCAL ref: >= 0 interior index, < 0 ~local triangle
+    int32_t n_interior = 0;
+    int32_t max_depth = 0;         // deepest interior level (root = 1); 0 for a one-triangle mesh
+    float bmin[3], bmax[3];
+};
+
+// Copies and validates the reference-layout node array. Returns false and sets err on malformed input.
+bool tree_from_reference_nodes(const hpt_bvh_node* nodes, int32_t nnodes, int32_t ntri, HostTree& out, std::string& err);
+// Binned SAH over triangle boxes/centroids (used when the host hands no tree, and for synthetic large scenes).
+void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, HostTree& out);
+// Tight refit + breadth-first renumbering + packing.  Child refs are LOCAL to the mesh; the caller rebases them.
+bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_idx, const float* normals, const uint32_t* nrm_idx,
+                  const float* uvw, const uint32_t* uv_idx, int32_t ntri, FlatMesh& out, std::string& err);

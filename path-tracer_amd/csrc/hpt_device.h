@@ -1,0 +1,105 @@
+// hpt_device.h -- data layout in HBM shared by the host-side flattener and the gfx950 kernels.
+//
+// Everything the kernels read is plain float4 / int arrays ("SoA of 16-byte quads"):
+//   Node64 : 4 x float4 per interior BVH2 node = one 64-byte record holding BOTH child boxes and child refs
+//            q0 = (left.min.xyz,  as_float(left_ref))   q1 = (left.max.xyz,  as_float(right_ref))
+//            q2 = (right.min.xyz, 0)                    q3 = (right.max.xyz, 0)
+//            child ref >= 0: index of an interior node (global over all meshes), < 0: ~(global triangle index).
+//            Leaves (bvh.rs:19-22) carry exactly one primitive, so they are folded into their parent's refs.
+//            Interior nodes of one mesh are stored in breadth-first order (top levels first => cacheable prefix).
+//   Tri48  : 3 x float4 per triangle: (a.xyz,0) (b-a,0) (c-a,0)  -- the operands of geometry.rs:188-199
+//   TriShade: 7 x float4 per triangle: a,b,c (get_point), n0,n1,n2 (get_normal), t0,t1,t2 (get_texture_vertex),
+//            27 floats + 1 pad, fetched once per closest hit by the shade stage only.
+#pragma once
+#include <stdint.h>
+
+#define HPT_BLOCK 256          // threads per workgroup: 4 wave64
+#define HPT_NODE_QUADS 4
+#define HPT_TRI_QUADS 3
+#define HPT_TRISHADE_QUADS 7
+#define HPT_MISS_INST 0x7fffffffu
+#define HPT_MAX_DEPTH_LIMIT 64   // max bounces (size of the per-depth live-count array)
+
+struct DMesh {
+    int32_t root_ref;     // ref of the root (interior index or ~tri for a one-triangle mesh)
+    int32_t tri_base;     // global index of this mesh's triangle 0
+    int32_t ntri;
+    int32_t stack_need;   // traversal stack entries needed (tree depth + 1)
+    float bmin[3], bmax[3];   // tight root box
+    int32_t pad[2];
+};
+
+// one level of the Node chain of an instance (scene.rs:102-105 Transform), rows of 3x3 matrices as float4
+struct DXformInv {   // extend: to_local(v) = Minv * (v - t)       (scene.rs:278-280)
+    float r0[4], r1[4], r2[4];   // (Minv row r, t[r])
+};
+struct DXformFwd {   // shade: from_local(v) = M*v + t (scene.rs:282), normal = normalize(Minv^T n) (scene.rs:286)
+    float m0[4], m1[4], m2[4];   // (M row r, t[r])
+    float n0[4], n1[4], n2[4];   // (Minv^T row r, 0)
+};
+
+struct DInstance {   // one Node with an object, in the reference's DFS visiting order
+    int32_t geom, mesh, material, node_id;
+    int32_t xf_first, xf_count;   // chain: outermost ancestor first
+    int32_t pad[2];
+};
+
+struct DTexture {
+    int32_t kind, image;
+    float color[3], color1[3], color2[3];
+    float minv[9];    // row-major inverse of the texture matrix (r*3+c)
+    float t[3];
+};
+struct DMaterial {
+    DTexture diffuse, reflection, refraction;
+    float emission[3];
+    float refl_gloss, refr_gloss, ior;
+};
+struct DImage {
+    uint64_t offset;   // byte offset into the image pool
+    int32_t w, h;
+};
+struct DCamera {      // main.rs:43-53 frame, computed on the host in the reference's f32 order
+    float a[3], right[3], up[3], pos[3];
+    float pixel_width, pixel_height, dof;
+    uint32_t w, h;
+};
+
+struct DScene {
+    const float4* nodes;
+    const float4* tris;
+    const float4* trishade;
+    const DMesh* meshes;
+    const DInstance* instances;
+    const DXformInv* xinv;
+    const DXformFwd* xfwd;
+    const DMaterial* materials;
+    const DImage* images;
+    const uint8_t* image_pool;
+    int32_t n_instances, n_meshes;
+    DTexture background, environment;
+    DCamera cam;
+};
+
+// wavefront queues (SoA).  A path keeps its identity (path id = pixel_slot * S + s) in ray_d.w.
+struct DQueue {
+    float4* ray_o;   // (origin.xyz, roulette weight)                       scene.rs:130 `weight`
+    float4* ray_d;   // (dir.xyz, as_float(path id))
+    float4* thr;     // (throughput.rgb, 0): product of n.dot(new_dir)*albedo/p over the bounces so far
+};
+
+struct DPass {
+    DQueue q[2];
+    float4* hit;         // (t, u, v, as_float(global tri or -1))
+    uint32_t* hit_inst;  // instance | side<<31, HPT_MISS_INST on miss
+    float4* radiance;    // per path id: (L.rgb, 0)
+    uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2] live paths per depth
+    const float2* halton;        // [S] (halton(i,2), halton(i,3)) of this pass's samples
+    const uint32_t* pixel_list;  // adaptive: active pixels of this pass (NULL = all pixels, slot == pixel)
+    uint32_t n_slots;            // pixels in this pass
+    uint32_t S;                  // samples per pixel in this pass
+    uint32_t first_sample;       // Halton index of sample s is first_sample + s + 1
+    uint32_t seed;
+    int32_t max_depth;
+    unsigned long long* stat;    // [0] rays, [1] nodes, [2] tris, [3] inst tests, [4] primary rays
+};

@@ -1,0 +1,707 @@
+// hpt_kernels.hip -- gfx950 (MI355X, wave64) kernels of the render core.
+//
+// Wavefront path tracer replacing the recursive per-pixel integrator of the reference:
+//   k_raygen  : main.rs:65-85          (per (pixel,sample) primary ray, Halton jitter + square-lens sample)
+//   k_extend  : scene.rs:190-208,242-275, geometry.rs:30-97,132-221, bvh.rs:148-281  (closest hit)
+//   k_shade   : scene.rs:126-188,211-225,298-358,394-429 (+ stream compaction: ballot + wave prefix + 1 atomic/wave)
+//   k_resolve : main.rs:90-100,109-110 (per-pixel sum over samples in sample order, optional min/max)
+//   k_trace_rays / k_scene_intersect : parity / test entries (Mesh::intersect, Scene::intersect)
+//
+// Numerics: compiled with -ffp-contract=off.  Everything that decides a hit (triangle, sphere, plane, the node
+// transform chain) keeps the reference's operation order with IEEE divide/sqrt, so t,u,v and hit ids are
+// bit-identical to the CPU oracle.  Only the BVH box culling uses explicit fma + reciprocal (it never decides a hit:
+// boxes are conservative supersets of their triangles).  MFMA is not used: there is no dense contraction here.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "hpt_device.h"
+#include "hpt_launch.h"
+
+#define PI_F 3.14159265358979323846f
+#define HPT_INF __builtin_inff()
+
+// ------------------------------------------------------------------------------------------------ vector helpers
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 divs3(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// cgmath dot: (x + y) + z
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// cgmath normalize: v * (1 / |v|)
+__device__ __forceinline__ f3 normalize3(f3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f3 xyz(float4 q) { return mk3(q.x, q.y, q.z); }
+// row-dot of a float4 row (xyz) with v in cgmath order
+__device__ __forceinline__ float rowdot(const float* r, f3 v) { return (r[0] * v.x + r[1] * v.y) + r[2] * v.z; }
+
+// Rust f32::min/max semantics (NaN-ignoring); fminf/fmaxf have the same
+__device__ __forceinline__ float rmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float rmax(float a, float b) { return fmaxf(a, b); }
+
+// ------------------------------------------------------------------------------------------------ RNG / Halton
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct RngKey { uint32_t k1, k2; };
+__device__ __forceinline__ RngKey rng_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    RngKey k;
+    k.k1 = mix32(pixel + mix32(seed));
+    k.k2 = mix32(sample ^ 0x5bd1e995U ^ (seed * 0x9E3779B9U));
+    return k;
+}
+__device__ __forceinline__ float rng_f32(RngKey k, uint32_t dim) {
+    uint32_t h = mix32(k.k1 ^ mix32(k.k2 + dim * 0x9E3779B9U));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ transforms
+// scene.rs:278-280 with the inverse precomputed once per instance level (the reference inverts per call; same value)
+__device__ __forceinline__ f3 to_local(const DXformInv& X, f3 v) {
+    f3 w = mk3(v.x - X.r0[3], v.y - X.r1[3], v.z - X.r2[3]);
+    return mk3(rowdot(X.r0, w), rowdot(X.r1, w), rowdot(X.r2, w));
+}
+// scene.rs:228-232 applied through the whole ancestor chain, outermost first
+__device__ __forceinline__ void ray_to_local(const DScene& sc, const DInstance& in, f3& o, f3& d) {
+    for (int k = 0; k < in.xf_count; ++k) {
+        const DXformInv& X = sc.xinv[in.xf_first + k];
+        f3 lp = to_local(X, o);
+        f3 lq = to_local(X, add3(o, d));
+        d = sub3(lq, lp);
+        o = lp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ primitives
+// geometry.rs:188-221, operand order kept; ab/ac are precomputed on the host as b-a, c-a in f32 (same values)
+__device__ __forceinline__ bool intersect_triangle(f3 a, f3 ab, f3 ac, f3 pos, f3 dir, float& t, float& u, float& v, int& side) {
+    f3 pvec = cross3(dir, ac);
+    float det = dot3(ab, pvec);
+    if (fabsf(det) < 1.0e-8f) return false;
+    f3 tvec = sub3(pos, a);
+    u = dot3(tvec, pvec) / det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 qvec = cross3(tvec, ab);
+    v = dot3(dir, qvec) / det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot3(ac, qvec) / det;
+    if (t < 0.0f) return false;
+    side = det > 0.0f ? 1 : 0;
+    return true;
+}
+// geometry.rs:36-55 (t and side only; normal/uv are recomputed by the shade stage for the closest hit)
+__device__ __forceinline__ bool intersect_sphere(f3 pos, f3 dir, float& t, int& side) {
+    float pos_dot_dir = dot3(pos, dir);
+    float dir_len_sqr = dot3(dir, dir);
+    float disc = 4.0f * (pos_dot_dir * pos_dot_dir) - 4.0f * dir_len_sqr * (dot3(pos, pos) - 1.0f);
+    if (!(disc > 0.0f)) return false;
+    float ds = sqrtf(disc);
+    float t1 = (-2.0f * pos_dot_dir + ds) / (2.0f * dir_len_sqr);
+    float t2 = (-2.0f * pos_dot_dir - ds) / (2.0f * dir_len_sqr);
+    if (!(t1 > 0.0f || t2 > 0.0f)) return false;
+    if (t1 > 0.0f && t2 > 0.0f) { side = 1; t = rmin(t1, t2); }
+    else { side = 0; t = rmax(t1, t2); }
+    return true;
+}
+// geometry.rs:74-78,84
+__device__ __forceinline__ bool intersect_plane(f3 pos, f3 dir, float& t, int& side) {
+    t = -(pos.z / dir.z);
+    if (!(t > 0.0f)) return false;
+    float px = pos.x + t * dir.x, py = pos.y + t * dir.y;
+    if (!(-1.0f < px && px < 1.0f && -1.0f < py && py < 1.0f)) return false;
+    side = pos.z > 0.0f ? 1 : 0;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ BVH traversal
+struct RayBox { float idx, idy, idz, oxi, oyi, ozi; };
+__device__ __forceinline__ float safe_dir(float v) { return fabsf(v) < 1.0e-30f ? copysignf(1.0e-30f, v) : v; }
+__device__ __forceinline__ RayBox make_raybox(f3 o, f3 d) {
+    RayBox r;
+    r.idx = 1.0f / safe_dir(d.x); r.idy = 1.0f / safe_dir(d.y); r.idz = 1.0f / safe_dir(d.z);
+    r.oxi = o.x * r.idx; r.oyi = o.y * r.idy; r.ozi = o.z * r.idz;
+    return r;
+}
+// slab test (bvh.rs:225-281 semantics + the two culls the reference lacks: box behind the origin, box beyond bound)
+__device__ __forceinline__ bool box_hit(const RayBox& rb, float3 bmin, float3 bmax, float bound, float& tin) {
+    float t0x = __builtin_fmaf(bmin.x, rb.idx, -rb.oxi), t1x = __builtin_fmaf(bmax.x, rb.idx, -rb.oxi);
+    float t0y = __builtin_fmaf(bmin.y, rb.idy, -rb.oyi), t1y = __builtin_fmaf(bmax.y, rb.idy, -rb.oyi);
+    float t0z = __builtin_fmaf(bmin.z, rb.idz, -rb.ozi), t1z = __builtin_fmaf(bmax.z, rb.idz, -rb.ozi);
+    tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    // conservative: a few ulps of slack so that rounding in the fma/reciprocal form never culls a box the
+    // reference's divide form (bvh.rs:233-234) would have entered
+    float slack = 4.0e-7f * fmaxf(fabsf(tin), fabsf(tout));
+    return (tin <= tout + slack) && (tout + slack >= 0.0f) && (tin - slack <= bound);
+}
+
+// Closest hit of one ray against one mesh (geometry.rs:132-158 + bvh.rs:148-204).
+//  - candidate accepted iff t <= tm (later candidate wins ties, geometry.rs:142-146) and t < tlimit
+//    (a mesh hit only replaces the scene-level nearest on strict <, scene.rs:196,251)
+//  - stk: this lane's column of the LDS stack (stride HPT_BLOCK ints)
+template <bool COUNT>
+__device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                              int root_ref, f3 o, f3 d, float tlimit,
+                                              float& tm, int& prim, float& bu, float& bv, int& side,
+                                              int* stk, unsigned& n_int, unsigned& n_tri) {
+    const RayBox rb = make_raybox(o, d);
+    int sp = 0;
+    int ref = root_ref;
+    for (;;) {
+        if (ref >= 0) {
+            const float4* nq = nodes + (size_t)ref * HPT_NODE_QUADS;
+            const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+            if (COUNT) n_int++;
+            const float bound = fminf(tm, tlimit);
+            float tinL, tinR;
+            const bool hitL = box_hit(rb, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound, tinL);
+            const bool hitR = box_hit(rb, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound, tinR);
+            const int l = __float_as_int(q0.w), r = __float_as_int(q1.w);
+            if (hitL && hitR) {
+                const bool lfirst = tinL < tinR;
+                stk[sp * HPT_BLOCK] = lfirst ? r : l;
+                sp++;
+                ref = lfirst ? l : r;
+                continue;
+            } else if (hitL) { ref = l; continue; }
+            else if (hitR) { ref = r; continue; }
+        } else {
+            const int tri = ~ref;
+            const float4* tq = tris + (size_t)tri * HPT_TRI_QUADS;
+            const float4 a = tq[0], ab = tq[1], ac = tq[2];
+            if (COUNT) n_tri++;
+            float t, u, v; int s;
+            if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), o, d, t, u, v, s)) {
+                if (t <= tm && t < tlimit) { tm = t; prim = tri; bu = u; bv = v; side = s; }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        ref = stk[sp * HPT_BLOCK];
+    }
+}
+
+struct Hit { float t, u, v; int prim; uint32_t inst_side; };
+
+// scene.rs:190-208 over the flattened instance list (reference DFS order => same tie winners)
+template <bool COUNT>
+__device__ __forceinline__ Hit scene_closest_hit(const DScene& sc, f3 o, f3 d, int* stk,
+                                                 unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+    for (int i = 0; i < sc.n_instances; ++i) {
+        const DInstance in = sc.instances[i];
+        f3 lo = o, ld = d;
+        ray_to_local(sc, in, lo, ld);
+        if (COUNT) n_inst++;
+        if (in.geom == 1) {
+            float t; int s;
+            if (intersect_sphere(lo, ld, t, s) && t < h.t) { h.t = t; h.prim = -1; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
+        } else if (in.geom == 2) {
+            float t; int s;
+            if (intersect_plane(lo, ld, t, s) && t < h.t) { h.t = t; h.prim = -1; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
+        } else {
+            const DMesh m = sc.meshes[in.mesh];
+            const RayBox rb = make_raybox(lo, ld);
+            float tin;
+            if (box_hit(rb, make_float3(m.bmin[0], m.bmin[1], m.bmin[2]), make_float3(m.bmax[0], m.bmax[1], m.bmax[2]), h.t, tin)) {
+                float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, s = 0;
+                traverse_mesh<COUNT>(sc.nodes, sc.tris, m.root_ref, lo, ld, h.t, tm, prim, bu, bv, s, stk, n_int, n_tri);
+                if (prim >= 0) { h.t = tm; h.u = bu; h.v = bv; h.prim = prim; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
+            }
+        }
+    }
+    return h;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ k_trace_rays
+template <bool COUNT>
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_trace_rays(const float4* __restrict__ nodes, const float4* __restrict__ tris, DMesh mesh, long long n,
+             const float4* __restrict__ org, const float4* __restrict__ dir, float4* __restrict__ hit,
+             uint8_t* __restrict__ side_out, unsigned long long* stat) {
+    extern __shared__ int lds_stack[];
+    int* stk = lds_stack + threadIdx.x;
+    unsigned n_int = 0, n_tri = 0;
+    for (long long base = (long long)blockIdx.x * HPT_BLOCK; base < n; base += (long long)gridDim.x * HPT_BLOCK) {
+        const long long i = base + threadIdx.x;
+        if (i < n) {
+            const f3 o = xyz(org[i]), d = xyz(dir[i]);
+            float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, s = 0;
+            const RayBox rb = make_raybox(o, d);
+            float tin;
+            if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin))
+                traverse_mesh<COUNT>(nodes, tris, mesh.root_ref, o, d, HPT_INF, tm, prim, bu, bv, s, stk, n_int, n_tri);
+            float4 h;
+            if (prim >= 0) h = make_float4(tm, bu, bv, __int_as_float(prim - mesh.tri_base));
+            else h = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+            hit[i] = h;
+            side_out[i] = (uint8_t)s;
+        }
+    }
+    if (COUNT) {
+        unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stat[1], a); atomicAdd(&stat[2], b); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_raygen
+// main.rs:65-85.  path id = slot * S + s; slot -> pixel through pixel_list in adaptive passes.
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_raygen(DScene sc, DPass ps) {
+    const DCamera& c = sc.cam;
+    const f3 a = ld3(c.a), right = ld3(c.right), up = ld3(c.up), cpos = ld3(c.pos);
+    const uint32_t n = ps.n_slots * ps.S;
+    for (uint32_t path = blockIdx.x * HPT_BLOCK + threadIdx.x; path < n; path += gridDim.x * HPT_BLOCK) {
+        const uint32_t slot = path / ps.S, s = path - slot * ps.S;
+        const uint32_t pixel = ps.pixel_list ? ps.pixel_list[slot] : slot;
+        const uint32_t x = pixel % c.w, y = pixel / c.w;
+        const uint32_t sample = ps.first_sample + s + 1;
+        const RngKey key = rng_key(ps.seed, pixel, sample);
+        const float2 hal = ps.halton[s];
+        // top-left corner of the pixel (main.rs:65)
+        f3 top_left = sub3(add3(a, scale3(right, (float)x * c.pixel_width)), scale3(up, (float)y * c.pixel_height));
+        const float r1 = rng_f32(key, 0), r2 = rng_f32(key, 1);
+        const float eye_x = 2.0f * r1 - 1.0f, eye_y = 2.0f * r2 - 1.0f;
+        f3 p = sub3(add3(top_left, scale3(right, hal.x * c.pixel_width)), scale3(up, hal.y * c.pixel_height));
+        f3 eye = add3(add3(cpos, scale3(right, eye_x * c.dof)), scale3(up, eye_y * c.dof));
+        f3 dir = normalize3(sub3(p, eye));
+        ps.q[0].ray_o[path] = make_float4(eye.x, eye.y, eye.z, 1.0f);
+        ps.q[0].ray_d[path] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(path));
+        ps.q[0].thr[path] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        ps.radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ps.counts[0] = n;
+}
+
+// ------------------------------------------------------------------------------------------------ k_extend
+template <bool COUNT>
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_extend(DScene sc, DPass ps, int depth) {
+    extern __shared__ int lds_stack[];
+    int* stk = lds_stack + threadIdx.x;
+    const DQueue& q = ps.q[depth & 1];
+    const uint32_t n = ps.counts[depth];
+    unsigned n_int = 0, n_tri = 0, n_inst = 0;
+    for (uint32_t base = blockIdx.x * HPT_BLOCK; base < n; base += gridDim.x * HPT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < n) {
+            const float4 o4 = q.ray_o[i], d4 = q.ray_d[i];
+            const Hit h = scene_closest_hit<COUNT>(sc, xyz(o4), xyz(d4), stk, n_int, n_tri, n_inst);
+            ps.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+            ps.hit_inst[i] = h.inst_side;
+        }
+    }
+    if (COUNT) {
+        unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
+                           c = wave_sum<unsigned long long>(n_inst);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&ps.stat[1], a); atomicAdd(&ps.stat[2], b); atomicAdd(&ps.stat[3], c); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shading helpers
+// scene.rs:378-392 (`as i32` saturates, NaN -> 0: v_cvt_i32_f32 does the same)
+__device__ __forceinline__ float trunc_i32(float x) {
+    if (x != x) return 0.0f;
+    if (x >= 2147483648.0f) return 2147483648.0f;
+    if (x <= -2147483648.0f) return -2147483648.0f;
+    return (float)(int)x;
+}
+__device__ __forceinline__ f3 unit_clamp(f3 p) {
+    float x = p.x - trunc_i32(p.x); if (x < 0.0f) x += 1.0f;
+    float y = p.y - trunc_i32(p.y); if (y < 0.0f) y += 1.0f;
+    float z = p.z - trunc_i32(p.z); if (z < 0.0f) z += 1.0f;
+    return mk3(x, y, z);
+}
+__device__ __forceinline__ f3 u8_as_color(const uint8_t* c) {   // scene.rs:369-376
+    return mk3(rmin(rmax((float)c[0] / 255.0f, 0.0f), 1.0f), rmin(rmax((float)c[1] / 255.0f, 0.0f), 1.0f),
+               rmin(rmax((float)c[2] / 255.0f, 0.0f), 1.0f));
+}
+// scene.rs:299-301 + 312-358
+__device__ f3 texture_sample(const DScene& sc, const DTexture& tx, f3 point) {
+    const f3 color = ld3(tx.color);
+    if (tx.kind == 0) return color;   // Blank: colour * (1,1,1)
+    f3 w = mk3(point.x - tx.t[0], point.y - tx.t[1], point.z - tx.t[2]);
+    f3 lp = mk3(rowdot(tx.minv + 0, w), rowdot(tx.minv + 3, w), rowdot(tx.minv + 6, w));
+    f3 data;
+    if (tx.kind == 2) {
+        const DImage im = sc.images[tx.image];
+        const size_t width = (size_t)im.w, height = (size_t)im.h;
+        if (width + height == 0) return mul3(color, mk3(0, 0, 0));
+        const uint8_t* px = sc.image_pool + im.offset;
+        f3 c = unit_clamp(lp);
+        float x = c.x * (float)width, y = c.y * (float)height;
+        size_t x1 = (size_t)x, y1 = (size_t)y;
+        float xt = x - (float)x1, yt = y - (float)y1;
+        x1 = x1 % width; y1 = y1 % height;
+        size_t x2 = (x1 + 1) % width, y2 = (y1 + 1) % height;
+        f3 p00 = u8_as_color(px + 3 * (y1 * width + x1)), p10 = u8_as_color(px + 3 * (y1 * width + x2));
+        f3 p01 = u8_as_color(px + 3 * (y2 * width + x1)), p11 = u8_as_color(px + 3 * (y2 * width + x2));
+        data = scale3(p00, (1.0f - xt) * (1.0f - yt));
+        data = add3(data, scale3(p10, xt * (1.0f - yt)));
+        data = add3(data, scale3(p01, (1.0f - xt) * yt));
+        data = add3(data, scale3(p11, xt * yt));
+    } else {
+        f3 c = unit_clamp(lp);
+        data = ((c.x < 0.5f && c.y < 0.5f) || (c.x > 0.5f && c.y > 0.5f)) ? ld3(tx.color1) : ld3(tx.color2);
+    }
+    return mul3(color, data);
+}
+// scene.rs:303-305
+__device__ __forceinline__ f3 texture_sample_environment(const DScene& sc, const DTexture& tx, f3 dir) {
+    if (tx.kind == 0) return ld3(tx.color);
+    return texture_sample(sc, tx, mk3(0.5f + atan2f(dir.y, dir.x) / (2.0f * PI_F), 0.5f - asinf(-dir.z) / PI_F, 0.0f));
+}
+// scene.rs:211-213
+__device__ __forceinline__ f3 reflect_ray(f3 vec, f3 normal) {
+    return normalize3(add3(neg3(vec), scale3(normal, 2.0f * dot3(normal, vec))));
+}
+// scene.rs:215-225
+__device__ __forceinline__ bool refract_ray(f3 vec, f3 normal, float n1, float n2, f3& out) {
+    float n = n1 / n2;
+    float ndv = dot3(normal, vec);
+    f3 s = scale3(sub3(scale3(normal, ndv), vec), n);
+    float cos_sqr = 1.0f - (n * n) * (1.0f - ndv * ndv);
+    if (cos_sqr >= 0.0f) { out = normalize3(sub3(s, scale3(normal, sqrtf(cos_sqr)))); return true; }
+    return false;
+}
+__device__ __forceinline__ void smallest_axis_basis(f3 vec, f3& u, f3& v) {   // scene.rs:395-404
+    float xa = fabsf(vec.x), ya = fabsf(vec.y), za = fabsf(vec.z);
+    f3 axis;
+    if (xa < ya && xa < za) axis = mk3(1, 0, 0);
+    else if (ya < za) axis = mk3(0, 1, 0);
+    else axis = mk3(0, 0, 1);
+    u = normalize3(cross3(vec, axis));
+    v = normalize3(cross3(vec, u));
+}
+// scene.rs:394-411 (max_angle) / 413-429 (hemisphere: z_min = 0 exactly)
+__device__ __forceinline__ f3 sample_about(f3 vec, float z, float r1) {
+    f3 u, v; smallest_axis_basis(vec, u, v);
+    float theta = r1 * 2.0f * PI_F;
+    f3 o = add3(scale3(vec, z), scale3(add3(scale3(u, cosf(theta)), scale3(v, sinf(theta))), cosf(asinf(z))));
+    return normalize3(o);
+}
+
+struct WorldHit { f3 pos, normal, uv; int side; int material; int node_id; int prim_local; };
+
+// Rebuild the reference HitInfo (scene.rs:87-93) of the closest hit and carry it out through the node chain
+// (scene.rs:263-271): geometry.rs:57-65 sphere, :79-85 plane, :147-153 mesh.
+__device__ WorldHit world_hit(const DScene& sc, f3 o, f3 d, float t, float bu, float bv, int prim, uint32_t inst_side) {
+    WorldHit w;
+    const DInstance in = sc.instances[inst_side & 0x7fffffffu];
+    w.side = (int)(inst_side >> 31);
+    w.material = in.material; w.node_id = in.node_id; w.prim_local = -1;
+    f3 lo = o, ld = d;
+    ray_to_local(sc, in, lo, ld);
+    f3 pos, normal, uv;
+    if (in.geom == 1) {
+        pos = add3(lo, scale3(ld, t));
+        normal = normalize3(pos);
+        uv = mk3(0.5f + atan2f(normal.y, normal.x) / (2.0f * PI_F), 0.5f - asinf(-normal.z) / PI_F, 0.0f);
+    } else if (in.geom == 2) {
+        pos = add3(lo, scale3(ld, t));
+        uv = mk3(0.5f + 0.5f * pos.x, 0.5f + 0.5f * pos.y, 0.0f);
+        normal = mk3(0, 0, 1);
+    } else {
+        const float* s = (const float*)(sc.trishade + (size_t)prim * HPT_TRISHADE_QUADS);
+        const float wgt = 1.0f - bu - bv;
+        pos = add3(add3(scale3(ld3(s + 0), wgt), scale3(ld3(s + 3), bu)), scale3(ld3(s + 6), bv));
+        normal = add3(add3(scale3(ld3(s + 9), wgt), scale3(ld3(s + 12), bu)), scale3(ld3(s + 15), bv));
+        uv = add3(add3(scale3(ld3(s + 18), wgt), scale3(ld3(s + 21), bu)), scale3(ld3(s + 24), bv));
+        w.prim_local = prim - sc.meshes[in.mesh].tri_base;
+    }
+    for (int k = in.xf_count - 1; k >= 0; --k) {
+        const DXformFwd& X = sc.xfwd[in.xf_first + k];
+        pos = mk3(rowdot(X.m0, pos) + X.m0[3], rowdot(X.m1, pos) + X.m1[3], rowdot(X.m2, pos) + X.m2[3]);
+        normal = normalize3(mk3(rowdot(X.n0, normal), rowdot(X.n1, normal), rowdot(X.n2, normal)));
+    }
+    w.pos = pos; w.normal = normal; w.uv = uv;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------ k_scene_intersect
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_scene_intersect(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
+                  int* __restrict__ node, int* __restrict__ prim, float* __restrict__ t, uint8_t* __restrict__ side,
+                  float4* __restrict__ pos, float4* __restrict__ normal, float4* __restrict__ uvw) {
+    extern __shared__ int lds_stack[];
+    int* stk = lds_stack + threadIdx.x;
+    unsigned c0 = 0, c1 = 0, c2 = 0;
+    for (long long base = (long long)blockIdx.x * HPT_BLOCK; base < n; base += (long long)gridDim.x * HPT_BLOCK) {
+        const long long i = base + threadIdx.x;
+        if (i < n) {
+            const f3 o = xyz(org[i]), d = xyz(dir[i]);
+            const Hit h = scene_closest_hit<false>(sc, o, d, stk, c0, c1, c2);
+            if (h.inst_side == HPT_MISS_INST) {
+                node[i] = -1; prim[i] = -1; t[i] = 0.0f; side[i] = 0;
+                pos[i] = make_float4(0, 0, 0, 0); normal[i] = make_float4(0, 0, 0, 0); uvw[i] = make_float4(0, 0, 0, 0);
+            } else {
+                const WorldHit w = world_hit(sc, o, d, h.t, h.u, h.v, h.prim, h.inst_side);
+                node[i] = w.node_id; prim[i] = w.prim_local; t[i] = h.t; side[i] = (uint8_t)w.side;
+                pos[i] = make_float4(w.pos.x, w.pos.y, w.pos.z, 0);
+                normal[i] = make_float4(w.normal.x, w.normal.y, w.normal.z, 0);
+                uvw[i] = make_float4(w.uv.x, w.uv.y, w.uv.z, 0);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_shade
+// One bounce of Scene::cast (scene.rs:130-188) in forward (throughput) form + append of the surviving paths to the
+// next queue.  radiance[path] += throughput * emission replaces the recursion's `color = emission + f * next`.
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_shade(DScene sc, DPass ps, int depth) {
+    const DQueue& qi = ps.q[depth & 1];
+    const DQueue& qo = ps.q[(depth + 1) & 1];
+    const uint32_t n = ps.counts[depth];
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * HPT_BLOCK; base < n; base += gridDim.x * HPT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0), nthr = make_float4(0, 0, 0, 0);
+        if (i < n) {
+            const float4 o4 = qi.ray_o[i], d4 = qi.ray_d[i], thr4 = qi.thr[i];
+            const float4 h4 = ps.hit[i];
+            const uint32_t inst_side = ps.hit_inst[i];
+            const uint32_t path = __float_as_uint(d4.w);
+            const f3 o = xyz(o4), d = xyz(d4), thr = xyz(thr4);
+            const float weight = o4.w;
+            const uint32_t slot = path / ps.S, s = path - slot * ps.S;
+            const uint32_t pixel = ps.pixel_list ? ps.pixel_list[slot] : slot;
+            f3 add = mk3(0, 0, 0);
+            bool have_add = false;
+            if (inst_side == HPT_MISS_INST) {
+                if (depth == 0) {   // scene.rs:127: background at the image-space sample position (main.rs:85)
+                    if (sc.background.kind != 0 || sc.background.color[0] != 0.0f || sc.background.color[1] != 0.0f || sc.background.color[2] != 0.0f) {
+                        const float2 hal = ps.halton[s];
+                        const uint32_t x = pixel % sc.cam.w, y = pixel / sc.cam.w;
+                        add = texture_sample(sc, sc.background, mk3(((float)x + hal.x) / (float)sc.cam.w, ((float)y + hal.y) / (float)sc.cam.h, 0.0f));
+                        have_add = true;
+                    }
+                } else {            // scene.rs:173
+                    if (sc.environment.kind != 0 || sc.environment.color[0] != 0.0f || sc.environment.color[1] != 0.0f || sc.environment.color[2] != 0.0f) {
+                        add = mul3(thr, texture_sample_environment(sc, sc.environment, d));
+                        have_add = true;
+                    }
+                }
+            } else {
+                const WorldHit w = world_hit(sc, o, d, h4.x, h4.y, h4.z, __float_as_int(h4.w), inst_side);
+                const DMaterial& mat = sc.materials[w.material];
+                const f3 diffuse = texture_sample(sc, mat.diffuse, w.uv);
+                const f3 reflection = texture_sample(sc, mat.reflection, w.uv);
+                const f3 refraction = texture_sample(sc, mat.refraction, w.uv);
+                const f3 normal = w.side ? w.normal : neg3(w.normal);
+                float n1, n2;
+                if (w.side) { n1 = 1.0f; n2 = mat.ior; } else { n1 = mat.ior; n2 = 1.0f; }
+                float r0 = (n1 - n2) / (n1 + n2); r0 = r0 * r0;
+                float c1 = 1.0f - dot3(normal, neg3(d));
+                float c2 = c1 * c1;
+                const float ar = r0 + (1.0f - r0) * (c2 * c2 * c1);
+                float p_diffuse = (diffuse.x + diffuse.y + diffuse.z) / 3.0f;
+                float p_refraction = (1.0f - ar) * (refraction.x + refraction.y + refraction.z) / 3.0f;
+                float p_reflection = (1.0f + ar) * (reflection.x + reflection.y + reflection.z) / 3.0f;   // sic (scene.rs:154)
+                const float p_range = p_diffuse + p_reflection + p_refraction;
+                const f3 emission = ld3(mat.emission);
+                if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f) { add = mul3(thr, emission); have_add = true; }
+                if (depth < ps.max_depth && p_range != 0.0f) {
+                    const RngKey key = rng_key(ps.seed, pixel, ps.first_sample + s + 1);
+                    const uint32_t d0 = 2u + 4u * (uint32_t)depth;
+                    if (!(rng_f32(key, d0) > weight)) {    // Russian roulette, no compensation (scene.rs:161)
+                        p_diffuse = p_diffuse / p_range;
+                        p_reflection = p_reflection / p_range;
+                        p_refraction = p_refraction / p_range;
+                        const float rnd = rng_f32(key, d0 + 1);
+                        const float ra = rng_f32(key, d0 + 2), rb = rng_f32(key, d0 + 3);
+                        f3 new_dir = mk3(0, 0, 0), albedo = mk3(0, 0, 0); float p = 0.0f; bool picked = true;
+                        if (rnd < p_diffuse) {
+                            new_dir = sample_about(normal, ra, rb);
+                            albedo = diffuse; p = p_diffuse;
+                        } else if (rnd < p_diffuse + p_reflection) {
+                            const float z_min = cosf(mat.refl_gloss);
+                            new_dir = sample_about(reflect_ray(neg3(d), normal), z_min + ra * (1.0f - z_min), rb);
+                            albedo = reflection; p = p_reflection;
+                        } else if (rnd < p_diffuse + p_reflection + p_refraction) {
+                            f3 rd;
+                            if (!refract_ray(neg3(d), normal, n1, n2, rd)) rd = reflect_ray(neg3(d), normal);
+                            const float z_min = cosf(mat.refr_gloss);
+                            new_dir = sample_about(rd, z_min + ra * (1.0f - z_min), rb);
+                            albedo = refraction; p = p_refraction;
+                        } else picked = false;
+                        if (picked) {
+                            const float ndot = dot3(normal, new_dir);
+                            // f = n.dot(new_dir) * albedo / p   (scene.rs:172,176,180)
+                            const f3 f = divs3(scale3(albedo, ndot), p);
+                            const f3 nt = mul3(thr, f);
+                            const f3 np = add3(w.pos, scale3(new_dir, 0.01f));   // BIAS scene.rs:122
+                            no = make_float4(np.x, np.y, np.z, weight * p);
+                            nd = make_float4(new_dir.x, new_dir.y, new_dir.z, d4.w);
+                            nthr = make_float4(nt.x, nt.y, nt.z, 0.0f);
+                            alive = true;
+                        }
+                    }
+                }
+            }
+            if (have_add) {
+                float4 L = ps.radiance[path];
+                L.x += add.x; L.y += add.y; L.z += add.z;
+                ps.radiance[path] = L;
+            }
+        }
+        // stream compaction: 64-bit ballot + prefix popcount, one atomic per wave
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&ps.counts[depth + 1], (uint32_t)__popcll(mask));
+            wbase = __shfl(wbase, 0);
+            if (alive) {
+                const uint32_t dst = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                qo.ray_o[dst] = no; qo.ray_d[dst] = nd; qo.thr[dst] = nthr;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_resolve
+// main.rs:109: per-pixel sum over samples in sample order, continued across passes (acc = sum so far);
+// main.rs:90-100: optional running per-channel min/max over the raw samples (adaptive mode).
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_resolve(DPass ps, float* __restrict__ accum, float* __restrict__ minmax) {
+    for (uint32_t slot = blockIdx.x * HPT_BLOCK + threadIdx.x; slot < ps.n_slots; slot += gridDim.x * HPT_BLOCK) {
+        const uint32_t pixel = ps.pixel_list ? ps.pixel_list[slot] : slot;
+        float r = accum[3 * (size_t)pixel], g = accum[3 * (size_t)pixel + 1], b = accum[3 * (size_t)pixel + 2];
+        float mn[3], mx[3];
+        if (minmax) for (int c = 0; c < 3; ++c) { mn[c] = minmax[6 * (size_t)pixel + c]; mx[c] = minmax[6 * (size_t)pixel + 3 + c]; }
+        const float4* L = ps.radiance + (size_t)slot * ps.S;
+        for (uint32_t s = 0; s < ps.S; ++s) {
+            const float4 v = L[s];
+            r += v.x; g += v.y; b += v.z;
+            if (minmax) {
+                if (v.x < mn[0]) mn[0] = v.x;
+                if (v.x > mx[0]) mx[0] = v.x;
+                if (v.y < mn[1]) mn[1] = v.y;
+                if (v.y > mx[1]) mx[1] = v.y;
+                if (v.z < mn[2]) mn[2] = v.z;
+                if (v.z > mx[2]) mx[2] = v.z;
+            }
+        }
+        accum[3 * (size_t)pixel] = r; accum[3 * (size_t)pixel + 1] = g; accum[3 * (size_t)pixel + 2] = b;
+        if (minmax) for (int c = 0; c < 3; ++c) { minmax[6 * (size_t)pixel + c] = mn[c]; minmax[6 * (size_t)pixel + 3 + c] = mx[c]; }
+    }
+}
+
+// live-count bookkeeping at the end of a pass: rays traced = sum of the per-depth queue lengths
+__global__ void k_finish_pass(DPass ps) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int d = 0; d <= ps.max_depth; ++d) tot += ps.counts[d];
+        ps.stat[0] += tot;
+        ps.stat[4] += ps.counts[0];
+    }
+}
+
+// main.rs:101 decision per pixel after a round: writes the still-active pixel list for the next round
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_adaptive_select(const uint32_t* __restrict__ in_list, uint32_t n_in, const float* __restrict__ minmax,
+                  float thr_r, float thr_g, float thr_b, uint32_t* __restrict__ out_list, uint32_t* __restrict__ out_count,
+                  uint32_t* __restrict__ samples_per_px, uint32_t num_samples_next) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * HPT_BLOCK; base < n_in; base += gridDim.x * HPT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        bool more = false; uint32_t pixel = 0;
+        if (i < n_in) {
+            pixel = in_list ? in_list[i] : i;
+            const float* m = minmax + 6 * (size_t)pixel;
+            more = ((m[3] - m[0]) / (m[0] + m[3]) > thr_r) || ((m[4] - m[1]) / (m[1] + m[4]) > thr_g) || ((m[5] - m[2]) / (m[2] + m[5]) > thr_b);
+            if (more) samples_per_px[pixel] = num_samples_next;
+        }
+        const unsigned long long mask = __ballot(more);
+        if (mask) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(out_count, (uint32_t)__popcll(mask));
+            wbase = __shfl(wbase, 0);
+            if (more) out_list[wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = pixel;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_fill_f32(float* p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * HPT_BLOCK) p[i] = v;
+}
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_fill_u32(uint32_t* p, size_t n, uint32_t v) {
+    for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * HPT_BLOCK) p[i] = v;
+}
+// rgb[i] = accum[i] / samples[pixel]   (main.rs:110)
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_divide(const float* __restrict__ accum, const uint32_t* __restrict__ samples, float* __restrict__ out, uint32_t npix, float fixed_n) {
+    for (uint32_t p = blockIdx.x * HPT_BLOCK + threadIdx.x; p < npix; p += gridDim.x * HPT_BLOCK) {
+        const float nsmp = samples ? (float)samples[p] : fixed_n;
+        out[3 * (size_t)p] = accum[3 * (size_t)p] / nsmp;
+        out[3 * (size_t)p + 1] = accum[3 * (size_t)p + 1] / nsmp;
+        out[3 * (size_t)p + 2] = accum[3 * (size_t)p + 2] / nsmp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline int grid_for(uint64_t n, int max_blocks) {
+    uint64_t b = (n + HPT_BLOCK - 1) / HPT_BLOCK;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)max_blocks) b = (uint64_t)max_blocks;
+    return (int)b;
+}
+static inline size_t stack_bytes(int stack_entries) { return (size_t)stack_entries * HPT_BLOCK * sizeof(int); }
+
+void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
+                     const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat) {
+    const int grid = grid_for((uint64_t)n, max_blocks);
+    const size_t lds = stack_bytes(mesh.stack_need);
+    if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, mesh, n, org, dir, hit, side, stat);
+    else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, mesh, n, org, dir, hit, side, stat);
+}
+void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
+                          const float4* dir, int* node, int* prim, float* t, uint8_t* side, float4* pos, float4* normal, float4* uvw) {
+    hipLaunchKernelGGL(k_scene_intersect, dim3(grid_for((uint64_t)n, max_blocks)), dim3(HPT_BLOCK), stack_bytes(stack_entries), st,
+                       sc, n, org, dir, node, prim, t, side, pos, normal, uvw);
+}
+void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
+}
+void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
+    const size_t lds = stack_bytes(stack_entries);
+    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth);
+}
+void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth) {
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth);
+}
+void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(ps.n_slots, max_blocks)), dim3(HPT_BLOCK), 0, st, ps, accum, minmax);
+}
+void hptk_finish_pass(hipStream_t st, const DPass& ps) { hipLaunchKernelGGL(k_finish_pass, dim3(1), dim3(64), 0, st, ps); }
+void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_list, uint32_t n_in, const float* minmax, const float thr[3],
+                          uint32_t* out_list, uint32_t* out_count, uint32_t* samples_per_px, uint32_t num_samples_next) {
+    hipLaunchKernelGGL(k_adaptive_select, dim3(grid_for(n_in, max_blocks)), dim3(HPT_BLOCK), 0, st, in_list, n_in, minmax, thr[0], thr[1], thr[2],
+                       out_list, out_count, samples_per_px, num_samples_next);
+}
+void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v) {
+    hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, p, n, v);
+}
+void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32_t v) {
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, p, n, v);
+}
+void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n) {
+    hipLaunchKernelGGL(k_divide, dim3(grid_for(npix, max_blocks)), dim3(HPT_BLOCK), 0, st, accum, samples, out, npix, fixed_n);
+}

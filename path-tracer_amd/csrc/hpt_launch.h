@@ -1,0 +1,19 @@
+// hpt_launch.h -- host-callable launchers of the kernels in hpt_kernels.hip (all asynchronous on `st`).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hpt_device.h"
+
+void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
+                     const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat);
+void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
+                          const float4* dir, int* node, int* prim, float* t, uint8_t* side, float4* pos, float4* normal, float4* uvw);
+void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps);
+void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count);
+void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth);
+void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax);
+void hptk_finish_pass(hipStream_t st, const DPass& ps);
+void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_list, uint32_t n_in, const float* minmax, const float thr[3],
+                          uint32_t* out_list, uint32_t* out_count, uint32_t* samples_per_px, uint32_t num_samples_next);
+void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v);
+void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32_t v);
+void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n);
