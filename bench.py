@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on its own configuration.
+
+metric   : Mrays/sec (primary + bounce segments traced per second), whole job over all ranks
+workload : configs[1] "Teapot scene 1920x1080, 1024 spp, max depth 8" -- tests/golden/scene.xml with the camera
+           resized to 1920x1080, fixed 1024 samples per pixel, seed 1, host-built reference BVH.
+step     : one full frame (all 1024 spp of every pixel).  With N ranks the samples of every pixel are split into N
+           contiguous ranges (strong scaling: the frame is fixed), each rank renders its range on its GPU and the float
+           accumulators are sum-reduced onto rank 0 with RCCL (torch.distributed backend "nccl"), inside the timed region.
+Inputs are resident in HBM before the timed region (the scene is committed once); the output stays on the device.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Extra objects on the JSON line: "roofline" (k_extend: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak)
+and "cpu_baseline" (the C restatement of the reference -- oracle/liboracle_fast.so -- on the host cores, rank 0, N=1).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+EXTEND_QUEUE_BYTES = 52    # per ray in k_extend itself: ray_o + ray_d read (32 B), hit + hit_inst written (20 B)
+
+
+def cpu_baseline(desc, spp, depth, seed):
+    """The oracle (kind "port": C restatement of the reference's algorithm, faithful mode -- reference tree with loose
+    boxes, no pruning, per-call matrix inversion) timed on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    lib = ol.load(fast=True)
+    sc = ol.OracleScene(lib, desc)
+    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "1024")))
+    r = sc.render(spp=spp, max_depth=depth, seed=seed, threads=threads)
+    st = r["stats"]
+    return {"value": round(st.rays / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
+            "sample": "%dx%d, samples 1..%d of 1024 spp, depth %d (%.1f M rays, %.1f s)" % (
+                desc.camera.width, desc.camera.height, spp, depth, st.rays / 1e6, st.seconds),
+            "samples_per_px_per_s": round(spp / st.seconds, 4)}, r["rgb"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--spp-per-pass", type=int, default=0)
+    ap.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--tree", choices=["host", "sah"], default="host", help="host: reference bvh.rs tree handed over (drop-in); sah: library-built")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the render core has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import hpt
+    from hpt import host_bvh, scene_io
+    from hpt.dist import sample_range
+
+    desc = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "scene.xml"))
+    desc.camera.width, desc.camera.height = args.width, args.height
+    ctx = hpt.Context(local_rank)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    tree = (lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if args.tree == "host" else None
+    scene = hpt.Scene(ctx, desc, host_bvh=tree)          # scene + flattened BVH replicated on every rank's HBM
+
+    npix = args.width * args.height
+    first, count = sample_range(rank, world, args.spp)
+    flags = hpt.RENDER_TIME_KERNELS
+    with torch.cuda.stream(stream):
+        accum = torch.zeros(npix * 3, device="cuda", dtype=torch.float32)
+        image = torch.zeros(npix * 3, device="cuda", dtype=torch.float32)
+
+        def step():
+            st = scene.render_device(accum.data_ptr(), want_stats=True, spp=count, first_sample=first, max_depth=args.depth,
+                                     seed=1, spp_per_pass=args.spp_per_pass, flags=flags)
+            if world > 1:
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)     # RCCL sum-reduce of the float accumulators over xGMI
+            if rank == 0:
+                torch.div(accum, float(args.spp), out=image)        # main.rs:110
+            return st
+
+        for _ in range(args.warmup):
+            step()
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = [step() for _ in range(args.steps)]
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+
+        rays_local = sum(s.rays_primary + s.rays_bounce for s in stats)
+        ext_s_local = sum(s.seconds_extend for s in stats)
+        ext_launches = sum(s.launches_extend for s in stats)
+        shade_s_local = sum(s.seconds_shade for s in stats)
+        vec = torch.tensor([elapsed, float(rays_local)], device="cuda", dtype=torch.float64)
+        if world > 1:
+            tmax = vec[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            rsum = vec[1:].clone(); dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+            elapsed, rays_total = float(tmax.item()), float(rsum.item())
+        else:
+            rays_total = float(rays_local)
+
+        # per-ray algorithmic bytes of k_extend from an instrumented (counters on), untimed run of the same kernel on
+        # a slice of this rank's samples: 64 B per interior node popped + 48 B per triangle tested + 64 B per instance
+        # record entered + the queue bytes the kernel itself moves (DESIGN.md "Roofline")
+        cst = scene.render_device(accum.data_ptr(), want_stats=True, spp=min(count, 4), first_sample=first, max_depth=args.depth, seed=1,
+                                  spp_per_pass=args.spp_per_pass, flags=hpt.RENDER_COUNTERS)
+        crays = cst.rays_primary + cst.rays_bounce
+        bytes_per_ray = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested + 64.0 * cst.inst_tests) / crays + EXTEND_QUEUE_BYTES
+        bvh_bytes_per_ray = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested) / crays
+
+    if rank == 0:
+        achieved = bytes_per_ray * rays_local / ext_s_local
+        line = {
+            "metric": "Mrays/sec (primary+bounce), teapot 1080p", "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "teapot scene.xml %dx%d, %d spp, max depth %d, 1 frame per step" % (args.width, args.height, args.spp, args.depth),
+                       "spp_per_rank": count, "bvh": "reference bvh.rs tree built on host, tight refit" if args.tree == "host" else "library SAH",
+                       "parallelism": "spp-split x%d + RCCL sum-reduce" % world},
+            "samples_per_px_per_s": round(args.spp * args.steps / elapsed, 3),
+            "rays_per_step": rays_total / args.steps,
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "bytes_per_ray": round(bytes_per_ray, 1), "bvh_bytes_per_ray": round(bvh_bytes_per_ray, 1),
+                         "bvh_fetch_frac": round(bvh_bytes_per_ray * rays_local / ext_s_local / HBM_PEAK, 4),
+                         "avg_launch_ms": round(ext_s_local / max(ext_launches, 1) * 1e3, 4), "launches": int(ext_launches),
+                         "extend_share_of_step": round(ext_s_local / (elapsed), 3), "shade_share_of_step": round(shade_s_local / elapsed, 3)},
+        }
+        if world == 1 and args.cpu_spp > 0:
+            cb, cpu_img = cpu_baseline(desc, args.cpu_spp, args.depth, 1)
+            line["cpu_baseline"] = cb
+            # sanity: the CPU sample is the first cpu_spp samples of the same frame -> must agree with the GPU's samples 1..cpu_spp
+            chk = scene.render(spp=args.cpu_spp, max_depth=args.depth, seed=1)["rgb"]
+            line["cpu_baseline"]["image_rel_rmse_vs_gpu"] = float(np.sqrt(((chk - cpu_img) ** 2).mean()) / cpu_img.mean())
+        print(json.dumps(line), flush=True)
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
