@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,7 @@ struct hpt_context {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int num_cus = 256;
     int max_blocks = 2048;
+    int extend_blocks = 1024;   // persistent grid of the traversal kernels (LDS-limited residency)
     std::vector<hipEvent_t> events;   // pool for HPT_RENDER_TIME_KERNELS
 };
 
@@ -84,14 +86,15 @@ struct hpt_scene {
     hpt_camera camera;
     bool have_camera = false, committed = false;
     // device side
-    DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_xinv, d_xfwd, d_materials, d_images, d_pool;
+    DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_meshinst, d_xinv, d_xfwd, d_materials, d_images, d_pool;
     std::vector<DMesh> h_meshes;
     DScene ds;
     int stack_entries = 1;
+    int n_xf = 0, n_mat = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
     DevBuf w_q[2][3], w_hit, w_hit_inst, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
     // trace workspace
-    DevBuf t_org, t_dir, t_hit, t_side, t_misc[7];
+    DevBuf t_org, t_dir, t_hit, t_side, t_misc[9];
 };
 
 static void identity_tex(hpt_texture& t) {   // load.rs:30-34
@@ -169,6 +172,8 @@ extern "C" int hpt_context_create(int device, hpt_context** out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->max_blocks = c->num_cus * 8;
+    c->extend_blocks = c->num_cus * 4;
+    if (const char* e = getenv("HPT_EXTEND_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->extend_blocks = c->num_cus * v; }
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     *out = c;
@@ -208,7 +213,7 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_xinv, &s->d_xfwd, &s->d_materials,
+    DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_materials,
                      &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
                      &s->w_accum, &s->w_minmax, &s->w_spp, &s->w_list[0], &s->w_list[1], &s->w_listcount, &s->w_out,
                      &s->t_org, &s->t_dir, &s->t_hit, &s->t_side};
@@ -364,8 +369,8 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         }
         DMesh dm; std::memset(&dm, 0, sizeof dm);
         dm.root_ref = rebase(fm.root_ref); dm.tri_base = (int32_t)tri_base; dm.ntri = m.n_tri;
-        dm.stack_need = fm.max_depth + 1;
-        if (dm.stack_need > 120) return fail(HPT_ERR_LIMIT, "bvh: tree depth %d exceeds the traversal stack limit (120); pass nodes=NULL to let the library build a balanced tree", fm.max_depth);
+        dm.stack_need = fm.max_depth + 2;   // deferred far children (<= interior depth) + the bottom sentinel
+        if (dm.stack_need > 40) return fail(HPT_ERR_LIMIT, "bvh: tree depth %d exceeds the traversal stack limit (40 entries of LDS per lane); pass nodes=NULL to let the library build a balanced tree", fm.max_depth);
         for (int k = 0; k < 3; ++k) { dm.bmin[k] = fm.bmin[k]; dm.bmax[k] = fm.bmax[k]; }
         s->stack_entries = std::max(s->stack_entries, dm.stack_need);
         s->h_meshes.push_back(dm);
@@ -374,9 +379,10 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         trishade.insert(trishade.end(), fm.trishade.begin(), fm.trishade.end());
     }
     // ---- instances in the reference's visiting order (scene.rs:193, :245-248): object first, then children
-    std::vector<DInstance> inst; std::vector<DXformInv> xinv; std::vector<DXformFwd> xfwd;
+    std::vector<DInstance> inst; std::vector<DXformInv> xinv; std::vector<DXformFwd> xfwd; std::vector<int32_t> meshinst;
     {
         struct Frame { int32_t node; size_t next_child; };
+        int32_t prev_top = -1;
         for (int32_t topid : s->top) {
             std::vector<Frame> stack{{topid, 0}};
             std::vector<int32_t> chain{topid};
@@ -386,6 +392,9 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
                 DInstance di; std::memset(&di, 0, sizeof di);
                 di.geom = n.geom; di.mesh = n.mesh; di.material = n.material; di.node_id = id;
                 di.xf_first = (int32_t)xinv.size(); di.xf_count = (int32_t)chain.size();
+                di.shared_top = (chain[0] == prev_top) ? 1 : 0;
+                prev_top = chain[0];
+                int level = 0;
                 for (int32_t cid : chain) {
                     const HostNode& cn = s->nodes[cid];
                     float inv[9];
@@ -396,8 +405,11 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
                         for (int c = 0; c < 3; ++c) { ir[r][c] = inv[c * 3 + r]; mr[r][c] = cn.m[c * 3 + r]; nr[r][c] = inv[r * 3 + c]; }
                         ir[r][3] = cn.t[r]; mr[r][3] = cn.t[r]; nr[r][3] = 0.0f;
                     }
+                    if (level < 2) di.lv[level] = xi;
+                    ++level;
                     xinv.push_back(xi); xfwd.push_back(xf);
                 }
+                if (di.geom == HPT_GEOM_MESH) meshinst.push_back((int32_t)inst.size());
                 inst.push_back(di);
                 return HPT_OK;
             };
@@ -430,16 +442,18 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         while (pool.size() % 16) pool.push_back(0);
     }
     CHK(upload(s->d_nodes, nodes, st)); CHK(upload(s->d_tris, tris, st)); CHK(upload(s->d_trishade, trishade, st));
-    CHK(upload(s->d_meshes, s->h_meshes, st)); CHK(upload(s->d_instances, inst, st));
+    CHK(upload(s->d_meshes, s->h_meshes, st)); CHK(upload(s->d_instances, inst, st)); CHK(upload(s->d_meshinst, meshinst, st));
     CHK(upload(s->d_xinv, xinv, st)); CHK(upload(s->d_xfwd, xfwd, st));
     CHK(upload(s->d_materials, mats, st)); CHK(upload(s->d_images, imgs, st)); CHK(upload(s->d_pool, pool, st));
     HIPCHK(hipStreamSynchronize(st));   // the staging vectors die at scope end
     DScene& d = s->ds;
     d.nodes = s->d_nodes.as<float4>(); d.tris = s->d_tris.as<float4>(); d.trishade = s->d_trishade.as<float4>();
-    d.meshes = s->d_meshes.as<DMesh>(); d.instances = s->d_instances.as<DInstance>();
+    d.meshes = s->d_meshes.as<DMesh>(); d.instances = s->d_instances.as<DInstance>(); d.mesh_instances = s->d_meshinst.as<int32_t>();
     d.xinv = s->d_xinv.as<DXformInv>(); d.xfwd = s->d_xfwd.as<DXformFwd>();
     d.materials = s->d_materials.as<DMaterial>(); d.images = s->d_images.as<DImage>(); d.image_pool = s->d_pool.as<uint8_t>();
     d.n_instances = (int32_t)inst.size(); d.n_meshes = (int32_t)s->h_meshes.size();
+    s->n_xf = (int)xinv.size(); s->n_mat = (int)mats.size();
+    d.n_mesh_instances = (int32_t)meshinst.size(); d.n_nodes = (int32_t)(nodes.size() / 16);
     conv_texture(s->background, d.background); conv_texture(s->environment, d.environment);
     camera_frame(s->camera, d.cam);
     s->committed = true;
@@ -472,7 +486,7 @@ extern "C" int hpt_trace_rays_device(hpt_scene* s, int32_t mesh_id, int64_t n, c
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, st));
     }
-    hptk_trace_rays(st, ctx->max_blocks, s->ds, s->h_meshes[mesh_id], n, (const float4*)org4, (const float4*)dir4, (float4*)hit4, (uint8_t*)side_out,
+    hptk_trace_rays(st, ctx->extend_blocks, s->ds, s->h_meshes[mesh_id], n, (const float4*)org4, (const float4*)dir4, (float4*)hit4, (uint8_t*)side_out,
                     count_visits != 0, d_stat);
     HIPCHK(hipGetLastError());
     if (stats) {
@@ -542,11 +556,12 @@ extern "C" int hpt_scene_intersect(hpt_scene* s, int64_t n, const float* org3, c
     pack4(org3, n, o4); pack4(dir3, n, d4);
     const size_t N = (size_t)n;
     CHK(s->t_org.ensure(N * 16)); CHK(s->t_dir.ensure(N * 16));
-    const size_t sizes[7] = {N * 4, N * 4, N * 4, N, N * 16, N * 16, N * 16};
-    for (int k = 0; k < 7; ++k) CHK(s->t_misc[k].ensure(sizes[k]));
+    const size_t sizes[9] = {N * 4, N * 4, N * 4, N, N * 16, N * 16, N * 16, N * 16, N * 4};
+    for (int k = 0; k < 9; ++k) CHK(s->t_misc[k].ensure(sizes[k]));
     HIPCHK(hipMemcpyAsync(s->t_org.p, o4.data(), N * 16, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(s->t_dir.p, d4.data(), N * 16, hipMemcpyHostToDevice, st));
-    hptk_scene_intersect(st, ctx->max_blocks, s->stack_entries, s->ds, n, s->t_org.as<float4>(), s->t_dir.as<float4>(), s->t_misc[0].as<int>(),
+    hptk_scene_intersect(st, ctx->extend_blocks, s->stack_entries, s->ds, n, s->t_org.as<float4>(), s->t_dir.as<float4>(), s->t_misc[7].as<float4>(),
+                         s->t_misc[8].as<uint32_t>(), s->t_misc[0].as<int>(),
                          s->t_misc[1].as<int>(), s->t_misc[2].as<float>(), s->t_misc[3].as<uint8_t>(), s->t_misc[4].as<float4>(),
                          s->t_misc[5].as<float4>(), s->t_misc[6].as<float4>());
     HIPCHK(hipGetLastError());
@@ -608,13 +623,14 @@ static int default_spp_per_pass(uint64_t npix, int want) {
 static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks) {
     hpt_context* ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(ps.counts, 0, (HPT_MAX_DEPTH_LIMIT + 2) * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(ps.counts, 0, (size_t)(HPT_MAX_DEPTH_LIMIT + 2) * HPT_SHARDS * sizeof(uint32_t), st));
     CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps); CHK(ev.end(st));
     const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
     const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
+    const int sblocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)ctx->max_blocks);
     for (int depth = 0; depth <= ps.max_depth; ++depth) {
         CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->stack_entries, s->ds, ps, depth, counters); CHK(ev.end(st));
-        CHK(ev.begin(2, st)); hptk_shade(st, blocks, s->ds, ps, depth); CHK(ev.end(st));
+        CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->ds, ps, depth, s->n_xf, s->n_mat); CHK(ev.end(st));
     }
     CHK(ev.begin(3, st)); hptk_resolve(st, ctx->max_blocks, ps, accum, minmax); CHK(ev.end(st));
     hptk_finish_pass(st, ps);
@@ -622,11 +638,16 @@ static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool c
     return HPT_OK;
 }
 
-static int ensure_pass_workspace(hpt_scene* s, uint64_t max_paths, DPass& ps) {
-    if (max_paths >= (1ull << 31)) return fail(HPT_ERR_LIMIT, "render: more than 2^31 paths per pass; lower spp_per_pass");
+static uint32_t shard_cap_for(uint64_t n_paths) {
+    const uint64_t chunks = (n_paths + HPT_BLOCK - 1) / HPT_BLOCK;
+    return (uint32_t)(((chunks + HPT_SHARDS - 1) / HPT_SHARDS) * HPT_BLOCK);
+}
+static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps) {
+    if (n_paths >= (1ull << 31) - (1ull << 20)) return fail(HPT_ERR_LIMIT, "render: more than 2^31 paths per pass; lower spp_per_pass");
+    const uint64_t max_paths = (uint64_t)shard_cap_for(n_paths) * HPT_SHARDS;   // slots of a sharded queue
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(s->w_q[a][k].ensure(max_paths * 16));
     CHK(s->w_hit.ensure(max_paths * 16)); CHK(s->w_hit_inst.ensure(max_paths * 4)); CHK(s->w_radiance.ensure(max_paths * 16));
-    CHK(s->w_counts.ensure((HPT_MAX_DEPTH_LIMIT + 2) * sizeof(uint32_t)));
+    CHK(s->w_counts.ensure((size_t)(HPT_MAX_DEPTH_LIMIT + 2) * HPT_SHARDS * sizeof(uint32_t)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = s->w_q[a][0].as<float4>(); ps.q[a].ray_d = s->w_q[a][1].as<float4>(); ps.q[a].thr = s->w_q[a][2].as<float4>(); }
     ps.hit = s->w_hit.as<float4>(); ps.hit_inst = s->w_hit_inst.as<uint32_t>(); ps.radiance = s->w_radiance.as<float4>();
@@ -669,7 +690,8 @@ static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, 
         ps.halton = s->w_halton.as<float2>() + done;
         ps.pixel_list = nullptr; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
         ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
-        CHK(run_pass(s, ps, accum, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->max_blocks));
+        ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
+        CHK(run_pass(s, ps, accum, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->extend_blocks));
         ++passes;
         if (per_sample_host) {
             rad.resize((size_t)npix * cur * 4);
@@ -781,7 +803,8 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
                 ps.halton = s->w_halton.as<float2>() + have + done;
                 ps.pixel_list = cur_list < 0 ? nullptr : s->w_list[cur_list].as<uint32_t>();
                 ps.n_slots = n_active; ps.S = (uint32_t)cur; ps.first_sample = (uint32_t)(have + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
-                CHK(run_pass(s, ps, accum, s->w_minmax.as<float>(), (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->max_blocks));
+                ps.shard_cap = shard_cap_for((uint64_t)n_active * cur);
+                CHK(run_pass(s, ps, accum, s->w_minmax.as<float>(), (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->extend_blocks));
                 if (stats) { stats->passes++; stats->samples += (uint64_t)n_active * cur; }
             }
             have = num_samples;
@@ -806,3 +829,7 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
     if (stats) return finish_stats(s, stats, ev, t0);
     return HPT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ tuning hooks
+// Not part of include/hpt.h: used by scripts/gpu_time.py for interleaved A/B runs inside one process.
+extern "C" void hpt_debug_set_extend_blocks(hpt_context* ctx, int per_cu) { if (ctx && per_cu >= 1 && per_cu <= 16) ctx->extend_blocks = ctx->num_cus * per_cu; }

@@ -19,6 +19,9 @@
 #define HPT_TRISHADE_QUADS 7
 #define HPT_MISS_INST 0x7fffffffu
 #define HPT_MAX_DEPTH_LIMIT 64   // max bounces (size of the per-depth live-count array)
+#define HPT_NODE_CACHE 128       // interior nodes staged in LDS per workgroup (breadth-first prefix of the node array)
+#define HPT_SHARDS 64            // segments per wavefront queue (one append counter each)
+#define HPT_QUEUE_CAP 512        // LDS work queue of k_extend: rays that entered a mesh box, waiting for traversal
 
 struct DMesh {
     int32_t root_ref;     // ref of the root (interior index or ~tri for a one-triangle mesh)
@@ -38,10 +41,12 @@ struct DXformFwd {   // shade: from_local(v) = M*v + t (scene.rs:282), normal = 
     float n0[4], n1[4], n2[4];   // (Minv^T row r, 0)
 };
 
-struct DInstance {   // one Node with an object, in the reference's DFS visiting order
+struct DInstance {   // one Node with an object, in the reference's DFS visiting order.  128 bytes, self-contained:
     int32_t geom, mesh, material, node_id;
-    int32_t xf_first, xf_count;   // chain: outermost ancestor first
-    int32_t pad[2];
+    int32_t xf_first, xf_count;   // chain in xinv[]/xfwd[]: outermost ancestor first
+    int32_t shared_top;           // 1: level 0 is the same Node as the previous instance's level 0 (reuse its local ray)
+    int32_t pad;
+    DXformInv lv[2];              // inline copy of chain levels 0 and 1 (deeper levels: xinv[xf_first + k])
 };
 
 struct DTexture {
@@ -71,12 +76,13 @@ struct DScene {
     const float4* trishade;
     const DMesh* meshes;
     const DInstance* instances;
+    const int32_t* mesh_instances;   // indices (into instances[]) of the mesh instances, ascending
     const DXformInv* xinv;
     const DXformFwd* xfwd;
     const DMaterial* materials;
     const DImage* images;
     const uint8_t* image_pool;
-    int32_t n_instances, n_meshes;
+    int32_t n_instances, n_meshes, n_mesh_instances, n_nodes;
     DTexture background, environment;
     DCamera cam;
 };
@@ -93,7 +99,8 @@ struct DPass {
     float4* hit;         // (t, u, v, as_float(global tri or -1))
     uint32_t* hit_inst;  // instance | side<<31, HPT_MISS_INST on miss
     float4* radiance;    // per path id: (L.rgb, 0)
-    uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2] live paths per depth
+    uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2][HPT_SHARDS] live paths per depth and queue segment
+    uint32_t shard_cap;  // slots per segment (multiple of HPT_BLOCK); a queue holds HPT_SHARDS * shard_cap slots
     const float2* halton;        // [S] (halton(i,2), halton(i,3)) of this pass's samples
     const uint32_t* pixel_list;  // adaptive: active pixels of this pass (NULL = all pixels, slot == pixel)
     uint32_t n_slots;            // pixels in this pass

@@ -68,15 +68,24 @@ __device__ __forceinline__ f3 to_local(const DXformInv& X, f3 v) {
     f3 w = mk3(v.x - X.r0[3], v.y - X.r1[3], v.z - X.r2[3]);
     return mk3(rowdot(X.r0, w), rowdot(X.r1, w), rowdot(X.r2, w));
 }
-// scene.rs:228-232 applied through the whole ancestor chain, outermost first
-__device__ __forceinline__ void ray_to_local(const DScene& sc, const DInstance& in, f3& o, f3& d) {
-    for (int k = 0; k < in.xf_count; ++k) {
-        const DXformInv& X = sc.xinv[in.xf_first + k];
-        f3 lp = to_local(X, o);
-        f3 lq = to_local(X, add3(o, d));
-        d = sub3(lq, lp);
-        o = lp;
+// scene.rs:228-232 for one level
+__device__ __forceinline__ void ray_level(const DXformInv& X, f3& o, f3& d) {
+    f3 lp = to_local(X, o);
+    f3 lq = to_local(X, add3(o, d));
+    d = sub3(lq, lp);
+    o = lp;
+}
+// levels 1.. of an instance's chain (level 0 is applied by the caller so that siblings can share it)
+__device__ __forceinline__ void ray_rest_levels(const DScene& sc, const DInstance& in, f3& o, f3& d) {
+    if (in.xf_count > 1) {
+        ray_level(in.lv[1], o, d);
+        for (int k = 2; k < in.xf_count; ++k) ray_level(sc.xinv[in.xf_first + k], o, d);
     }
+}
+// the whole ancestor chain, outermost first
+__device__ __forceinline__ void ray_to_local(const DScene& sc, const DInstance& in, f3& o, f3& d) {
+    ray_level(in.lv[0], o, d);
+    ray_rest_levels(sc, in, o, d);
 }
 
 // ------------------------------------------------------------------------------------------------ primitives
@@ -129,35 +138,47 @@ __device__ __forceinline__ RayBox make_raybox(f3 o, f3 d) {
     r.oxi = o.x * r.idx; r.oyi = o.y * r.idy; r.ozi = o.z * r.idz;
     return r;
 }
-// slab test (bvh.rs:225-281 semantics + the two culls the reference lacks: box behind the origin, box beyond bound)
+// slab test (bvh.rs:225-281 semantics + the two culls the reference lacks: box behind the origin, box beyond bound).
+// It never decides a hit: boxes are supersets of their triangles and the relative slack (1e-6 on tout and on the
+// bound) keeps the fma/reciprocal form from culling a box the reference's divide form (bvh.rs:233-234) enters.
 __device__ __forceinline__ bool box_hit(const RayBox& rb, float3 bmin, float3 bmax, float bound, float& tin) {
     float t0x = __builtin_fmaf(bmin.x, rb.idx, -rb.oxi), t1x = __builtin_fmaf(bmax.x, rb.idx, -rb.oxi);
     float t0y = __builtin_fmaf(bmin.y, rb.idy, -rb.oyi), t1y = __builtin_fmaf(bmax.y, rb.idy, -rb.oyi);
     float t0z = __builtin_fmaf(bmin.z, rb.idz, -rb.ozi), t1z = __builtin_fmaf(bmax.z, rb.idz, -rb.ozi);
     tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-    float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-    // conservative: a few ulps of slack so that rounding in the fma/reciprocal form never culls a box the
-    // reference's divide form (bvh.rs:233-234) would have entered
-    float slack = 4.0e-7f * fmaxf(fabsf(tin), fabsf(tout));
-    return (tin <= tout + slack) && (tout + slack >= 0.0f) && (tin - slack <= bound);
+    const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * 1.000001f;
+    return (tin <= tout) && (tout >= 0.0f) && (tin <= bound * 1.000001f);
 }
 
 // Closest hit of one ray against one mesh (geometry.rs:132-158 + bvh.rs:148-204).
-//  - candidate accepted iff t <= tm (later candidate wins ties, geometry.rs:142-146) and t < tlimit
-//    (a mesh hit only replaces the scene-level nearest on strict <, scene.rs:196,251)
+//  - candidate accepted iff t <= tm (later candidate wins ties inside a mesh, geometry.rs:142-146) and it would
+//    replace the scene-level nearest: t < tlimit, or t == tlimit when this instance comes EARLIER in the reference's
+//    visiting order than the holder of tlimit (tie_ok; scene.rs:196,251 keep the earlier node on equal t)
 //  - stk: this lane's column of the LDS stack (stride HPT_BLOCK ints)
+//  - ncache: LDS copy of the first n_cached Node64 records, one plane per quad (plane stride HPT_NODE_CACHE)
 template <bool COUNT>
 __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                              int root_ref, f3 o, f3 d, float tlimit,
+                                              const float4* ncache, int n_cached,
+                                              int root_ref, f3 o, f3 d, float tlimit, bool tie_ok,
                                               float& tm, int& prim, float& bu, float& bv, int& side,
                                               int* stk, unsigned& n_int, unsigned& n_tri) {
     const RayBox rb = make_raybox(o, d);
-    int sp = 0;
+    const int SENTINEL = (int)0x80000000;      // bottom of the stack: a "leaf" ref no triangle can have
+    stk[0] = SENTINEL;
+    int sp = 1;
     int ref = root_ref;
-    for (;;) {
+    // if-if loop.  (A while-while loop -- inner loop over interior nodes until every lane holds a leaf -- measured 47 %
+    // SLOWER here: leaves hold one triangle, so lanes that reach a leaf early idle; a reciprocal pre-filter in front of the
+    // triangle test's three IEEE divisions measured +-0: see DESIGN.md tuning log.)
+    while (ref != SENTINEL) {
         if (ref >= 0) {
-            const float4* nq = nodes + (size_t)ref * HPT_NODE_QUADS;
-            const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+            float4 q0, q1, q2, q3;
+            if (ref < n_cached) {
+                q0 = ncache[ref]; q1 = ncache[HPT_NODE_CACHE + ref]; q2 = ncache[2 * HPT_NODE_CACHE + ref]; q3 = ncache[3 * HPT_NODE_CACHE + ref];
+            } else {
+                const float4* nq = nodes + (size_t)ref * HPT_NODE_QUADS;
+                q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3];
+            }
             if (COUNT) n_int++;
             const float bound = fminf(tm, tlimit);
             float tinL, tinR;
@@ -169,9 +190,9 @@ __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, 
                 stk[sp * HPT_BLOCK] = lfirst ? r : l;
                 sp++;
                 ref = lfirst ? l : r;
-                continue;
-            } else if (hitL) { ref = l; continue; }
-            else if (hitR) { ref = r; continue; }
+            } else if (hitL) ref = l;
+            else if (hitR) ref = r;
+            else { --sp; ref = stk[sp * HPT_BLOCK]; }
         } else {
             const int tri = ~ref;
             const float4* tq = tris + (size_t)tri * HPT_TRI_QUADS;
@@ -179,45 +200,167 @@ __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, 
             if (COUNT) n_tri++;
             float t, u, v; int s;
             if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), o, d, t, u, v, s)) {
-                if (t <= tm && t < tlimit) { tm = t; prim = tri; bu = u; bv = v; side = s; }
+                if (t <= tm && (t < tlimit || (tie_ok && t == tlimit))) { tm = t; prim = tri; bu = u; bv = v; side = s; }
             }
+            --sp;
+            ref = stk[sp * HPT_BLOCK];
         }
-        if (sp == 0) break;
-        --sp;
-        ref = stk[sp * HPT_BLOCK];
     }
 }
 
 struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 
-// scene.rs:190-208 over the flattened instance list (reference DFS order => same tie winners)
+// ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
+//   [stack: stack_entries x HPT_BLOCK ints][node cache: 4 planes x HPT_NODE_CACHE float4][queue: HPT_QUEUE_CAP uint4][qn]
+struct Lds {
+    int* stack; float4* ncache; uint4* queue; unsigned* qn; int n_cached;
+};
+__device__ __forceinline__ Lds lds_carve(int stack_entries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Lds L;
+    L.stack = (int*)lds_raw;
+    L.ncache = (float4*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
+    L.queue = (uint4*)(L.ncache + 4 * HPT_NODE_CACHE);
+    L.qn = (unsigned*)(L.queue + HPT_QUEUE_CAP);
+    L.n_cached = 0;
+    return L;
+}
+// stage the breadth-first prefix of the node array (the top levels of the first mesh's tree) into LDS
+__device__ __forceinline__ void lds_load_nodes(Lds& L, const float4* __restrict__ nodes, int n_nodes) {
+    L.n_cached = n_nodes < HPT_NODE_CACHE ? n_nodes : HPT_NODE_CACHE;
+    for (int j = threadIdx.x; j < 4 * L.n_cached; j += HPT_BLOCK) L.ncache[(j & 3) * HPT_NODE_CACHE + (j >> 2)] = nodes[j];
+    __syncthreads();
+}
+
+// Mesh part of scene.rs:190-208 for one ray: mesh instances mesh_instances[mpos..] in visiting order, starting from
+// the best hit found so far.
 template <bool COUNT>
-__device__ __forceinline__ Hit scene_closest_hit(const DScene& sc, f3 o, f3 d, int* stk,
-                                                 unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
-    Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
-    for (int i = 0; i < sc.n_instances; ++i) {
-        const DInstance in = sc.instances[i];
+__device__ __forceinline__ void trace_mesh_instances(const DScene& sc, const Lds& L, int* stk, f3 o, f3 d, int mpos, Hit& h,
+                                                     unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    for (int m = mpos; m < sc.n_mesh_instances; ++m) {
+        const int i = sc.mesh_instances[m];
+        const DInstance* in = sc.instances + i;
         f3 lo = o, ld = d;
-        ray_to_local(sc, in, lo, ld);
-        if (COUNT) n_inst++;
-        if (in.geom == 1) {
-            float t; int s;
-            if (intersect_sphere(lo, ld, t, s) && t < h.t) { h.t = t; h.prim = -1; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
-        } else if (in.geom == 2) {
-            float t; int s;
-            if (intersect_plane(lo, ld, t, s) && t < h.t) { h.t = t; h.prim = -1; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
-        } else {
-            const DMesh m = sc.meshes[in.mesh];
-            const RayBox rb = make_raybox(lo, ld);
-            float tin;
-            if (box_hit(rb, make_float3(m.bmin[0], m.bmin[1], m.bmin[2]), make_float3(m.bmax[0], m.bmax[1], m.bmax[2]), h.t, tin)) {
-                float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, s = 0;
-                traverse_mesh<COUNT>(sc.nodes, sc.tris, m.root_ref, lo, ld, h.t, tm, prim, bu, bv, s, stk, n_int, n_tri);
-                if (prim >= 0) { h.t = tm; h.u = bu; h.v = bv; h.prim = prim; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
-            }
+        ray_level(in->lv[0], lo, ld);
+        const int nlev = in->xf_count;
+        if (nlev > 1) {
+            ray_level(in->lv[1], lo, ld);
+            for (int k = 2; k < nlev; ++k) ray_level(sc.xinv[in->xf_first + k], lo, ld);
+        }
+        if (COUNT && m > mpos) n_inst++;   // the first one was already counted by the analytic phase
+        const DMesh* mesh = sc.meshes + in->mesh;
+        const RayBox rb = make_raybox(lo, ld);
+        float tin;
+        if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
+            float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, s = 0;
+            const bool tie_ok = (uint32_t)i < (h.inst_side & 0x7fffffffu);
+            traverse_mesh<COUNT>(sc.nodes, sc.tris, L.ncache, L.n_cached, mesh->root_ref, lo, ld, h.t, tie_ok, tm, prim, bu, bv, s, stk, n_int, n_tri);
+            if (prim >= 0) { h.t = tm; h.u = bu; h.v = bv; h.prim = prim; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
         }
     }
-    return h;
+}
+
+// Sharded wavefront queues.  A queue of capacity shards*cap slots is split into `shards` segments; segment s holds
+// counts[s] live entries in slots [s*cap, s*cap+counts[s]).  Work item w of a kernel = chunk (w / shards) of segment
+// (w % shards); a persistent workgroup takes w = blockIdx.x, + gridDim.x, ...  Producers append to the segment they
+// consume from, so each of the `shards` append counters sees 1/shards of the atomics (one counter for the whole queue
+// serialises at ~11 ns per returning atomic: 130 k wave-appends per 8 M-path launch = 1.4 ms, the whole k_shade time).
+struct WorkView { const uint32_t* counts; uint32_t cap; uint32_t shards; uint32_t n_linear; };
+__device__ __forceinline__ uint32_t work_items(const WorkView& wv) { return wv.shards * (wv.cap / HPT_BLOCK); }
+__device__ __forceinline__ bool work_slot(const WorkView& wv, uint32_t w, uint32_t& slot) {
+    const uint32_t s = w % wv.shards, k = w / wv.shards;
+    const uint32_t cnt = wv.counts ? wv.counts[s] : wv.n_linear;
+    const uint32_t off = k * HPT_BLOCK + threadIdx.x;
+    slot = s * wv.cap + off;
+    return off < cnt;
+}
+
+// phase 1 for one ray: analytic instances + first mesh box entered.  Returns true when the ray must be queued.
+template <bool COUNT>
+__device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uint32_t slot, Hit& h, uint4& item, unsigned& n_inst) {
+    h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+    int mpos = -1, mcount = 0;
+    f3 lo0 = o, ld0 = d;
+    for (int k = 0; k < sc.n_instances; ++k) {
+        const DInstance& in = sc.instances[k];      // uniform address: scalar loads
+        if (!in.shared_top) { lo0 = o; ld0 = d; ray_level(in.lv[0], lo0, ld0); }
+        if (in.geom == 3) {
+            if (mpos < 0) {
+                f3 lo = lo0, ld = ld0;
+                ray_rest_levels(sc, in, lo, ld);
+                if (COUNT) n_inst++;
+                const DMesh& mesh = sc.meshes[in.mesh];
+                const RayBox rb = make_raybox(lo, ld);
+                float tin;
+                if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin)) mpos = mcount;
+            }
+            mcount++;
+        } else {
+            f3 lo = lo0, ld = ld0;
+            ray_rest_levels(sc, in, lo, ld);
+            if (COUNT) n_inst++;
+            float t; int s;
+            const bool ok = in.geom == 1 ? intersect_sphere(lo, ld, t, s) : intersect_plane(lo, ld, t, s);
+            if (ok && t < h.t) { h.t = t; h.inst_side = (uint32_t)k | ((uint32_t)s << 31); }   // ascending k: earlier wins ties
+        }
+    }
+    if (mpos >= 0) { item = make_uint4(slot, (uint32_t)mpos, __float_as_uint(h.t), h.inst_side); return true; }
+    return false;
+}
+
+// Closest hit over the rays of a (sharded) queue (scene.rs:190-208), workgroup-cooperative and persistent:
+//  phase 1 (all lanes, uniform control flow): every analytic instance (sphere / plane) in visiting order, plus the
+//          root-box test of the mesh instances; a ray that enters a mesh box is queued in LDS instead of traversed
+//  phase 2 (whenever HPT_BLOCK rays are queued): one queued ray per lane -> every lane of every wave walks a BVH
+//  Rays are identified by their slot i; results go to hit[i] / hit_inst[i] exactly once per ray.
+template <bool COUNT>
+__device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
+                                                  const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
+                                                  unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    int* stk = L.stack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    auto process_item = [&](uint4 it) {
+        const uint32_t i = it.x;
+        Hit h; h.t = __uint_as_float(it.z); h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = it.w;
+        trace_mesh_instances<COUNT>(sc, L, stk, xyz(ray_o[i]), xyz(ray_d[i]), (int)it.y, h, n_int, n_tri, n_inst);
+        hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+        hit_inst[i] = h.inst_side;
+    };
+    if (threadIdx.x == 0) *L.qn = 0;
+    __syncthreads();
+    const uint32_t total = work_items(wv);
+    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+        uint32_t i;
+        const bool valid = work_slot(wv, w, i);
+        bool queued = false;
+        uint4 item = make_uint4(0, 0, 0, 0);
+        if (valid) {
+            Hit h;
+            queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, h, item, n_inst);
+            if (!queued) { hit[i] = make_float4(h.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = h.inst_side; }
+        }
+        // append the queued rays: 64-bit ballot + prefix popcount, one LDS atomic per wave
+        const unsigned long long mask = __ballot(queued);
+        if (mask) {
+            unsigned wbase = 0;
+            if (lane == 0) wbase = atomicAdd(L.qn, (unsigned)__popcll(mask));
+            wbase = __shfl(wbase, 0);
+            if (queued) L.queue[wbase + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = item;
+        }
+        __syncthreads();
+        const unsigned cnt = *L.qn;
+        const bool flush = cnt >= HPT_BLOCK;
+        if (flush) item = L.queue[cnt - HPT_BLOCK + threadIdx.x];
+        __syncthreads();
+        if (flush) {
+            if (threadIdx.x == 0) *L.qn = cnt - HPT_BLOCK;
+            process_item(item);
+        }
+        __syncthreads();
+    }
+    const unsigned cnt = *L.qn;
+    for (unsigned start = 0; start < cnt; start += HPT_BLOCK)
+        if (start + threadIdx.x < cnt) process_item(L.queue[start + threadIdx.x]);
 }
 
 template <typename T>
@@ -229,11 +372,12 @@ __device__ __forceinline__ T wave_sum(T v) {
 // ------------------------------------------------------------------------------------------------ k_trace_rays
 template <bool COUNT>
 __global__ void __launch_bounds__(HPT_BLOCK)
-k_trace_rays(const float4* __restrict__ nodes, const float4* __restrict__ tris, DMesh mesh, long long n,
+k_trace_rays(const float4* __restrict__ nodes, const float4* __restrict__ tris, int n_nodes, int stack_entries, DMesh mesh, long long n,
              const float4* __restrict__ org, const float4* __restrict__ dir, float4* __restrict__ hit,
              uint8_t* __restrict__ side_out, unsigned long long* stat) {
-    extern __shared__ int lds_stack[];
-    int* stk = lds_stack + threadIdx.x;
+    Lds L = lds_carve(stack_entries);
+    lds_load_nodes(L, nodes, n_nodes);
+    int* stk = L.stack + threadIdx.x;
     unsigned n_int = 0, n_tri = 0;
     for (long long base = (long long)blockIdx.x * HPT_BLOCK; base < n; base += (long long)gridDim.x * HPT_BLOCK) {
         const long long i = base + threadIdx.x;
@@ -243,7 +387,7 @@ k_trace_rays(const float4* __restrict__ nodes, const float4* __restrict__ tris, 
             const RayBox rb = make_raybox(o, d);
             float tin;
             if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin))
-                traverse_mesh<COUNT>(nodes, tris, mesh.root_ref, o, d, HPT_INF, tm, prim, bu, bv, s, stk, n_int, n_tri);
+                traverse_mesh<COUNT>(nodes, tris, L.ncache, L.n_cached, mesh.root_ref, o, d, HPT_INF, false, tm, prim, bu, bv, s, stk, n_int, n_tri);
             float4 h;
             if (prim >= 0) h = make_float4(tm, bu, bv, __int_as_float(prim - mesh.tri_base));
             else h = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
@@ -278,32 +422,37 @@ k_raygen(DScene sc, DPass ps) {
         f3 p = sub3(add3(top_left, scale3(right, hal.x * c.pixel_width)), scale3(up, hal.y * c.pixel_height));
         f3 eye = add3(add3(cpos, scale3(right, eye_x * c.dof)), scale3(up, eye_y * c.dof));
         f3 dir = normalize3(sub3(p, eye));
-        ps.q[0].ray_o[path] = make_float4(eye.x, eye.y, eye.z, 1.0f);
-        ps.q[0].ray_d[path] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(path));
-        ps.q[0].thr[path] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        // chunk c of 256 consecutive paths goes to segment c % shards of the depth-0 queue
+        const uint32_t chunk = path / HPT_BLOCK, seg = chunk % HPT_SHARDS, k = chunk / HPT_SHARDS;
+        const uint32_t q = seg * ps.shard_cap + k * HPT_BLOCK + (path % HPT_BLOCK);
+        ps.q[0].ray_o[q] = make_float4(eye.x, eye.y, eye.z, 1.0f);
+        ps.q[0].ray_d[q] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(path));
+        ps.q[0].thr[q] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         ps.radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) ps.counts[0] = n;
+    if (blockIdx.x == 0 && threadIdx.x < HPT_SHARDS) {
+        // live entries of segment s at depth 0: its full chunks + (maybe) the globally last, partial chunk
+        const uint32_t chunks = (n + HPT_BLOCK - 1) / HPT_BLOCK, seg = threadIdx.x;
+        uint32_t cnt = 0;
+        if (seg < chunks) {
+            const uint32_t mine = (chunks - 1 - seg) / HPT_SHARDS + 1;          // chunks c = seg, seg + shards, ... < chunks
+            cnt = mine * HPT_BLOCK;
+            if ((chunks - 1) % HPT_SHARDS == seg) cnt -= chunks * HPT_BLOCK - n;   // the last chunk is mine and partial
+        }
+        ps.counts[seg] = cnt;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_extend
 template <bool COUNT>
 __global__ void __launch_bounds__(HPT_BLOCK)
-k_extend(DScene sc, DPass ps, int depth) {
-    extern __shared__ int lds_stack[];
-    int* stk = lds_stack + threadIdx.x;
+k_extend(DScene sc, DPass ps, int depth, int stack_entries) {
+    Lds L = lds_carve(stack_entries);
+    lds_load_nodes(L, sc.nodes, sc.n_nodes);
     const DQueue& q = ps.q[depth & 1];
-    const uint32_t n = ps.counts[depth];
+    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_SHARDS; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
-    for (uint32_t base = blockIdx.x * HPT_BLOCK; base < n; base += gridDim.x * HPT_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        if (i < n) {
-            const float4 o4 = q.ray_o[i], d4 = q.ray_d[i];
-            const Hit h = scene_closest_hit<COUNT>(sc, xyz(o4), xyz(d4), stk, n_int, n_tri, n_inst);
-            ps.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
-            ps.hit_inst[i] = h.inst_side;
-        }
-    }
+    block_closest_hit<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
                            c = wave_sum<unsigned long long>(n_inst);
@@ -390,7 +539,9 @@ __device__ __forceinline__ void smallest_axis_basis(f3 vec, f3& u, f3& v) {   //
 __device__ __forceinline__ f3 sample_about(f3 vec, float z, float r1) {
     f3 u, v; smallest_axis_basis(vec, u, v);
     float theta = r1 * 2.0f * PI_F;
-    f3 o = add3(scale3(vec, z), scale3(add3(scale3(u, cosf(theta)), scale3(v, sinf(theta))), cosf(asinf(z))));
+    float st, ct;
+    sincosf(theta, &st, &ct);
+    f3 o = add3(scale3(vec, z), scale3(add3(scale3(u, ct), scale3(v, st)), cosf(asinf(z))));
     return normalize3(o);
 }
 
@@ -398,13 +549,22 @@ struct WorldHit { f3 pos, normal, uv; int side; int material; int node_id; int p
 
 // Rebuild the reference HitInfo (scene.rs:87-93) of the closest hit and carry it out through the node chain
 // (scene.rs:263-271): geometry.rs:57-65 sphere, :79-85 plane, :147-153 mesh.
-__device__ WorldHit world_hit(const DScene& sc, f3 o, f3 d, float t, float bu, float bv, int prim, uint32_t inst_side) {
+// The per-instance tables world_hit / k_shade read per lane (divergent addresses).  k_shade stages them in LDS when the
+// scene is small (LDS_SCENE): an LDS read costs ~64 cycles instead of an L2 round trip per dependent hop.
+struct Tables { const DInstance* inst; const DXformInv* xinv; const DXformFwd* xfwd; const DMaterial* mats; };
+__device__ __forceinline__ Tables global_tables(const DScene& sc) { Tables T; T.inst = sc.instances; T.xinv = sc.xinv; T.xfwd = sc.xfwd; T.mats = sc.materials; return T; }
+
+__device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T, f3 o, f3 d, float t, float bu, float bv, int prim, uint32_t inst_side) {
     WorldHit w;
-    const DInstance in = sc.instances[inst_side & 0x7fffffffu];
+    const DInstance& in = T.inst[inst_side & 0x7fffffffu];
     w.side = (int)(inst_side >> 31);
     w.material = in.material; w.node_id = in.node_id; w.prim_local = -1;
     f3 lo = o, ld = d;
-    ray_to_local(sc, in, lo, ld);
+    ray_level(in.lv[0], lo, ld);
+    if (in.xf_count > 1) {
+        ray_level(in.lv[1], lo, ld);
+        for (int k = 2; k < in.xf_count; ++k) ray_level(T.xinv[in.xf_first + k], lo, ld);
+    }
     f3 pos, normal, uv;
     if (in.geom == 1) {
         pos = add3(lo, scale3(ld, t));
@@ -420,10 +580,10 @@ __device__ WorldHit world_hit(const DScene& sc, f3 o, f3 d, float t, float bu, f
         pos = add3(add3(scale3(ld3(s + 0), wgt), scale3(ld3(s + 3), bu)), scale3(ld3(s + 6), bv));
         normal = add3(add3(scale3(ld3(s + 9), wgt), scale3(ld3(s + 12), bu)), scale3(ld3(s + 15), bv));
         uv = add3(add3(scale3(ld3(s + 18), wgt), scale3(ld3(s + 21), bu)), scale3(ld3(s + 24), bv));
-        w.prim_local = prim - sc.meshes[in.mesh].tri_base;
+        w.prim_local = prim - sc.meshes[in.mesh].tri_base;   // only read by the test entry (dead code in k_shade)
     }
     for (int k = in.xf_count - 1; k >= 0; --k) {
-        const DXformFwd& X = sc.xfwd[in.xf_first + k];
+        const DXformFwd& X = T.xfwd[in.xf_first + k];
         pos = mk3(rowdot(X.m0, pos) + X.m0[3], rowdot(X.m1, pos) + X.m1[3], rowdot(X.m2, pos) + X.m2[3]);
         normal = normalize3(mk3(rowdot(X.n0, normal), rowdot(X.n1, normal), rowdot(X.n2, normal)));
     }
@@ -432,28 +592,34 @@ __device__ WorldHit world_hit(const DScene& sc, f3 o, f3 d, float t, float bu, f
 }
 
 // ------------------------------------------------------------------------------------------------ k_scene_intersect
+// test entry for Scene::intersect: the same workgroup-cooperative closest hit as k_extend, then the HitInfo rebuild
 __global__ void __launch_bounds__(HPT_BLOCK)
-k_scene_intersect(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
-                  int* __restrict__ node, int* __restrict__ prim, float* __restrict__ t, uint8_t* __restrict__ side,
-                  float4* __restrict__ pos, float4* __restrict__ normal, float4* __restrict__ uvw) {
-    extern __shared__ int lds_stack[];
-    int* stk = lds_stack + threadIdx.x;
+k_scene_closest(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
+                float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, int stack_entries) {
+    Lds L = lds_carve(stack_entries);
+    lds_load_nodes(L, sc.nodes, sc.n_nodes);
     unsigned c0 = 0, c1 = 0, c2 = 0;
-    for (long long base = (long long)blockIdx.x * HPT_BLOCK; base < n; base += (long long)gridDim.x * HPT_BLOCK) {
-        const long long i = base + threadIdx.x;
-        if (i < n) {
-            const f3 o = xyz(org[i]), d = xyz(dir[i]);
-            const Hit h = scene_closest_hit<false>(sc, o, d, stk, c0, c1, c2);
-            if (h.inst_side == HPT_MISS_INST) {
-                node[i] = -1; prim[i] = -1; t[i] = 0.0f; side[i] = 0;
-                pos[i] = make_float4(0, 0, 0, 0); normal[i] = make_float4(0, 0, 0, 0); uvw[i] = make_float4(0, 0, 0, 0);
-            } else {
-                const WorldHit w = world_hit(sc, o, d, h.t, h.u, h.v, h.prim, h.inst_side);
-                node[i] = w.node_id; prim[i] = w.prim_local; t[i] = h.t; side[i] = (uint8_t)w.side;
-                pos[i] = make_float4(w.pos.x, w.pos.y, w.pos.z, 0);
-                normal[i] = make_float4(w.normal.x, w.normal.y, w.normal.z, 0);
-                uvw[i] = make_float4(w.uv.x, w.uv.y, w.uv.z, 0);
-            }
+    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n;
+    wv.cap = (uint32_t)((n + HPT_BLOCK - 1) / HPT_BLOCK) * HPT_BLOCK;
+    block_closest_hit<false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2);
+}
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_scene_hitinfo(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
+                const float4* __restrict__ hit, const uint32_t* __restrict__ hit_inst,
+                int* __restrict__ node, int* __restrict__ prim, float* __restrict__ t, uint8_t* __restrict__ side,
+                float4* __restrict__ pos, float4* __restrict__ normal, float4* __restrict__ uvw) {
+    for (long long i = (long long)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * HPT_BLOCK) {
+        const float4 h = hit[i];
+        const uint32_t is = hit_inst[i];
+        if (is == HPT_MISS_INST) {
+            node[i] = -1; prim[i] = -1; t[i] = 0.0f; side[i] = 0;
+            pos[i] = make_float4(0, 0, 0, 0); normal[i] = make_float4(0, 0, 0, 0); uvw[i] = make_float4(0, 0, 0, 0);
+        } else {
+            const WorldHit w = world_hit(sc, global_tables(sc), xyz(org[i]), xyz(dir[i]), h.x, h.y, h.z, __float_as_int(h.w), is);
+            node[i] = w.node_id; prim[i] = w.prim_local; t[i] = h.x; side[i] = (uint8_t)w.side;
+            pos[i] = make_float4(w.pos.x, w.pos.y, w.pos.z, 0);
+            normal[i] = make_float4(w.normal.x, w.normal.y, w.normal.z, 0);
+            uvw[i] = make_float4(w.uv.x, w.uv.y, w.uv.z, 0);
         }
     }
 }
@@ -461,17 +627,40 @@ k_scene_intersect(DScene sc, long long n, const float4* __restrict__ org, const 
 // ------------------------------------------------------------------------------------------------ k_shade
 // One bounce of Scene::cast (scene.rs:130-188) in forward (throughput) form + append of the surviving paths to the
 // next queue.  radiance[path] += throughput * emission replaces the recursion's `color = emission + f * next`.
+template <bool LDS_SCENE>
 __global__ void __launch_bounds__(HPT_BLOCK)
-k_shade(DScene sc, DPass ps, int depth) {
+k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
+    Tables T;
+    if constexpr (LDS_SCENE) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+        DInstance* li = (DInstance*)lds_raw;
+        DXformInv* lxi = (DXformInv*)(li + sc.n_instances);
+        DXformFwd* lxf = (DXformFwd*)(lxi + n_xf);
+        DMaterial* lm = (DMaterial*)(lxf + n_xf);
+        const int wi = sc.n_instances * (int)(sizeof(DInstance) / 4), wxi = n_xf * (int)(sizeof(DXformInv) / 4),
+                  wxf = n_xf * (int)(sizeof(DXformFwd) / 4), wm = n_mat * (int)(sizeof(DMaterial) / 4);
+        for (int j = threadIdx.x; j < wi; j += HPT_BLOCK) ((uint32_t*)li)[j] = ((const uint32_t*)sc.instances)[j];
+        for (int j = threadIdx.x; j < wxi; j += HPT_BLOCK) ((uint32_t*)lxi)[j] = ((const uint32_t*)sc.xinv)[j];
+        for (int j = threadIdx.x; j < wxf; j += HPT_BLOCK) ((uint32_t*)lxf)[j] = ((const uint32_t*)sc.xfwd)[j];
+        for (int j = threadIdx.x; j < wm; j += HPT_BLOCK) ((uint32_t*)lm)[j] = ((const uint32_t*)sc.materials)[j];
+        __syncthreads();
+        T.inst = li; T.xinv = lxi; T.xfwd = lxf; T.mats = lm;
+    } else {
+        T = global_tables(sc);
+    }
     const DQueue& qi = ps.q[depth & 1];
     const DQueue& qo = ps.q[(depth + 1) & 1];
-    const uint32_t n = ps.counts[depth];
+    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_SHARDS; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
+    uint32_t* counts_out = ps.counts + (size_t)(depth + 1) * HPT_SHARDS;
     const int lane = threadIdx.x & 63;
-    for (uint32_t base = blockIdx.x * HPT_BLOCK; base < n; base += gridDim.x * HPT_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
+    const uint32_t total = work_items(wv);
+    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+        uint32_t i;
+        const bool valid = work_slot(wv, w, i);
+        const uint32_t seg = w % HPT_SHARDS;
         bool alive = false;
         float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0), nthr = make_float4(0, 0, 0, 0);
-        if (i < n) {
+        if (valid) {
             const float4 o4 = qi.ray_o[i], d4 = qi.ray_d[i], thr4 = qi.thr[i];
             const float4 h4 = ps.hit[i];
             const uint32_t inst_side = ps.hit_inst[i];
@@ -497,8 +686,8 @@ k_shade(DScene sc, DPass ps, int depth) {
                     }
                 }
             } else {
-                const WorldHit w = world_hit(sc, o, d, h4.x, h4.y, h4.z, __float_as_int(h4.w), inst_side);
-                const DMaterial& mat = sc.materials[w.material];
+                const WorldHit w = world_hit(sc, T, o, d, h4.x, h4.y, h4.z, __float_as_int(h4.w), inst_side);
+                const DMaterial& mat = T.mats[w.material];
                 const f3 diffuse = texture_sample(sc, mat.diffuse, w.uv);
                 const f3 reflection = texture_sample(sc, mat.reflection, w.uv);
                 const f3 refraction = texture_sample(sc, mat.refraction, w.uv);
@@ -563,10 +752,10 @@ k_shade(DScene sc, DPass ps, int depth) {
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&ps.counts[depth + 1], (uint32_t)__popcll(mask));
+            if (lane == 0) wbase = atomicAdd(&counts_out[seg], (uint32_t)__popcll(mask));   // survivors stay in their segment
             wbase = __shfl(wbase, 0);
             if (alive) {
-                const uint32_t dst = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                const uint32_t dst = seg * ps.shard_cap + wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                 qo.ray_o[dst] = no; qo.ray_d[dst] = nd; qo.thr[dst] = nthr;
             }
         }
@@ -605,9 +794,11 @@ k_resolve(DPass ps, float* __restrict__ accum, float* __restrict__ minmax) {
 __global__ void k_finish_pass(DPass ps) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long tot = 0;
-        for (int d = 0; d <= ps.max_depth; ++d) tot += ps.counts[d];
+        unsigned long long prim = 0;
+        for (int d = 0; d <= ps.max_depth; ++d)
+            for (int s = 0; s < HPT_SHARDS; ++s) { tot += ps.counts[d * HPT_SHARDS + s]; if (d == 0) prim += ps.counts[s]; }
         ps.stat[0] += tot;
-        ps.stat[4] += ps.counts[0];
+        ps.stat[4] += prim;
     }
 }
 
@@ -662,30 +853,37 @@ static inline int grid_for(uint64_t n, int max_blocks) {
     if (b > (uint64_t)max_blocks) b = (uint64_t)max_blocks;
     return (int)b;
 }
-static inline size_t stack_bytes(int stack_entries) { return (size_t)stack_entries * HPT_BLOCK * sizeof(int); }
+// dynamic LDS of the traversal kernels: stack + node cache + work queue + queue counter (see lds_carve)
+static inline size_t trav_lds_bytes(int stack_entries) {
+    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + HPT_QUEUE_CAP * sizeof(uint4) + 16;
+}
 
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
                      const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat) {
     const int grid = grid_for((uint64_t)n, max_blocks);
-    const size_t lds = stack_bytes(mesh.stack_need);
-    if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, mesh, n, org, dir, hit, side, stat);
-    else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, mesh, n, org, dir, hit, side, stat);
+    const size_t lds = trav_lds_bytes(mesh.stack_need);
+    if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, sc.n_nodes, mesh.stack_need, mesh, n, org, dir, hit, side, stat);
+    else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, sc.n_nodes, mesh.stack_need, mesh, n, org, dir, hit, side, stat);
 }
 void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
-                          const float4* dir, int* node, int* prim, float* t, uint8_t* side, float4* pos, float4* normal, float4* uvw) {
-    hipLaunchKernelGGL(k_scene_intersect, dim3(grid_for((uint64_t)n, max_blocks)), dim3(HPT_BLOCK), stack_bytes(stack_entries), st,
-                       sc, n, org, dir, node, prim, t, side, pos, normal, uvw);
+                          const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
+                          float4* pos, float4* normal, float4* uvw) {
+    const int grid = grid_for((uint64_t)n, max_blocks);
+    hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries), st, sc, n, org, dir, hit, hit_inst, stack_entries);
+    hipLaunchKernelGGL(k_scene_hitinfo, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, node, prim, t, side, pos, normal, uvw);
 }
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
 }
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
-    const size_t lds = stack_bytes(stack_entries);
-    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth);
+    const size_t lds = trav_lds_bytes(stack_entries);
+    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries);
 }
-void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth) {
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth);
+void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {
+    const size_t tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
+    if (tables <= 24 * 1024) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(HPT_BLOCK), tables, st, sc, ps, depth, n_xf, n_mat);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth, n_xf, n_mat);
 }
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax) {
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(ps.n_slots, max_blocks)), dim3(HPT_BLOCK), 0, st, ps, accum, minmax);

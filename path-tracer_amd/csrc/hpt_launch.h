@@ -6,10 +6,11 @@
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
                      const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat);
 void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
-                          const float4* dir, int* node, int* prim, float* t, uint8_t* side, float4* pos, float4* normal, float4* uvw);
+                          const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
+                          float4* pos, float4* normal, float4* uvw);
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps);
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count);
-void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth);
+void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat);
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax);
 void hptk_finish_pass(hipStream_t st, const DPass& ps);
 void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_list, uint32_t n_in, const float* minmax, const float thr[3],

@@ -188,7 +188,7 @@ class Context:
         check(lib.hpt_context_synchronize(self.h))
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.hpt_context_destroy(self.h)
             self.h = None
 
@@ -317,7 +317,7 @@ class Scene:
         return out
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.hpt_scene_destroy(self.h)
             self.h = None
 
