@@ -832,4 +832,5 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
 
 // ------------------------------------------------------------------------------------------------ tuning hooks
 // Not part of include/hpt.h: used by scripts/gpu_time.py for interleaved A/B runs inside one process.
+extern "C" void hpt_debug_set_refill(int lanes) { hptk_set_refill(lanes); }
 extern "C" void hpt_debug_set_extend_blocks(hpt_context* ctx, int per_cu) { if (ctx && per_cu >= 1 && per_cu <= 16) ctx->extend_blocks = ctx->num_cus * per_cu; }

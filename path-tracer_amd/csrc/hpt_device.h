@@ -19,9 +19,9 @@
 #define HPT_TRISHADE_QUADS 7
 #define HPT_MISS_INST 0x7fffffffu
 #define HPT_MAX_DEPTH_LIMIT 64   // max bounces (size of the per-depth live-count array)
-#define HPT_NODE_CACHE 128       // interior nodes staged in LDS per workgroup (breadth-first prefix of the node array)
+#define HPT_NODE_CACHE 0         // interior nodes staged in LDS per workgroup (breadth-first prefix of the node array)
 #define HPT_SHARDS 64            // segments per wavefront queue (one append counter each)
-#define HPT_QUEUE_CAP 512        // LDS work queue of k_extend: rays that entered a mesh box, waiting for traversal
+#define HPT_QUEUE_CAP 1024       // LDS work queue of k_extend: rays that entered a mesh box, waiting for traversal
 
 struct DMesh {
     int32_t root_ref;     // ref of the root (interior index or ~tri for a one-triangle mesh)

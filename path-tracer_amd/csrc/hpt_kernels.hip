@@ -176,7 +176,7 @@ __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, 
             if (ref < n_cached) {
                 q0 = ncache[ref]; q1 = ncache[HPT_NODE_CACHE + ref]; q2 = ncache[2 * HPT_NODE_CACHE + ref]; q3 = ncache[3 * HPT_NODE_CACHE + ref];
             } else {
-                const float4* nq = nodes + (size_t)ref * HPT_NODE_QUADS;
+                const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
                 q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3];
             }
             if (COUNT) n_int++;
@@ -195,12 +195,12 @@ __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, 
             else { --sp; ref = stk[sp * HPT_BLOCK]; }
         } else {
             const int tri = ~ref;
-            const float4* tq = tris + (size_t)tri * HPT_TRI_QUADS;
+            const float4* tq = tris + (uint32_t)tri * (uint32_t)HPT_TRI_QUADS;
             const float4 a = tq[0], ab = tq[1], ac = tq[2];
             if (COUNT) n_tri++;
             float t, u, v; int s;
             if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), o, d, t, u, v, s)) {
-                if (t <= tm && (t < tlimit || (tie_ok && t == tlimit))) { tm = t; prim = tri; bu = u; bv = v; side = s; }
+                if ((t < tm || (t == tm && tri < prim)) && (t < tlimit || (tie_ok && t == tlimit))) { tm = t; prim = tri; bu = u; bv = v; side = s; }
             }
             --sp;
             ref = stk[sp * HPT_BLOCK];
@@ -213,7 +213,7 @@ struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 // ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
 //   [stack: stack_entries x HPT_BLOCK ints][node cache: 4 planes x HPT_NODE_CACHE float4][queue: HPT_QUEUE_CAP uint4][qn]
 struct Lds {
-    int* stack; float4* ncache; uint4* queue; unsigned* qn; int n_cached;
+    int* stack; float4* ncache; uint4* queue; unsigned* qn; unsigned* qhead; int n_cached; int refill;
 };
 __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -222,11 +222,13 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     L.ncache = (float4*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
     L.queue = (uint4*)(L.ncache + 4 * HPT_NODE_CACHE);
     L.qn = (unsigned*)(L.queue + HPT_QUEUE_CAP);
-    L.n_cached = 0;
+    L.qhead = L.qn + 1;
+    L.n_cached = 0; L.refill = 16;
     return L;
 }
 // stage the breadth-first prefix of the node array (the top levels of the first mesh's tree) into LDS
 __device__ __forceinline__ void lds_load_nodes(Lds& L, const float4* __restrict__ nodes, int n_nodes) {
+    // HPT_NODE_CACHE == 0 disables the cache: a second, LDS-side wait per step cost more than the L2 latency it saved
     L.n_cached = n_nodes < HPT_NODE_CACHE ? n_nodes : HPT_NODE_CACHE;
     for (int j = threadIdx.x; j < 4 * L.n_cached; j += HPT_BLOCK) L.ncache[(j & 3) * HPT_NODE_CACHE + (j >> 2)] = nodes[j];
     __syncthreads();
@@ -308,6 +310,119 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
     return false;
 }
 
+// Phase 2 of block_closest_hit: drain the LDS queue (cnt items) with persistent lanes.  A lane owns one queued ray at a
+// time: it walks the BVHs of the mesh instances that ray still has to visit (trace order = visiting order) and writes
+// the final hit record.  The inner loop is nothing but traversal steps; the wave leaves it as soon as L.refill lanes
+// have finished their mesh, merges their results and hands them the next queued ray (node visits per ray are
+// heavy-tailed, 20..300: without the refill a wave runs as long as its slowest ray with most lanes idle).
+template <bool COUNT>
+__device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsigned cnt, const float4* __restrict__ ray_o,
+                                            const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
+                                            unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    int* stk = L.stack + threadIdx.x;
+    const int SENTINEL = (int)0x80000000;
+    const float4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ tris = sc.tris;
+    bool have = false, exhausted = false;
+    uint32_t slot = 0; int mpos = 0, first_mpos = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), lo = o, ld = d;
+    Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+    RayBox rb = make_raybox(o, d);
+    float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, side = 0, ref = SENTINEL, sp = 1, inst_idx = 0; bool tie_ok = false;
+    for (;;) {
+        // ---- lanes without a ray pull the next queued one
+        bool need_setup = false;
+        if (!exhausted) {
+            bool tried = false;
+            if (!have) {
+                tried = true;
+                const unsigned idx = atomicAdd(L.qhead, 1u);
+                if (idx < cnt) {
+                    const uint4 it = L.queue[idx];
+                    slot = it.x; mpos = first_mpos = (int)it.y;
+                    h.t = __uint_as_float(it.z); h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = it.w;
+                    o = xyz(ray_o[slot]); d = xyz(ray_d[slot]);
+                    have = true; need_setup = true;
+                }
+            }
+            exhausted = __ballot(tried && !have) != 0ull;
+        }
+        // ---- lanes whose mesh is finished merge its result and move on to the ray's next mesh instance
+        if (have && !need_setup && ref == SENTINEL) {
+            if (prim >= 0) { h.t = tm; h.u = bu; h.v = bv; h.prim = prim; h.inst_side = (uint32_t)inst_idx | ((uint32_t)side << 31); }
+            ++mpos;
+            need_setup = true;
+        }
+        // ---- setup: next mesh instance whose root box the ray enters, or retire the ray
+        if (need_setup) {
+            for (;;) {
+                if (mpos >= sc.n_mesh_instances) {
+                    hit[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+                    hit_inst[slot] = h.inst_side;
+                    have = false; ref = SENTINEL;
+                    break;
+                }
+                inst_idx = sc.mesh_instances[mpos];
+                const DInstance* in = sc.instances + inst_idx;
+                lo = o; ld = d;
+                ray_level(in->lv[0], lo, ld);
+                const int nlev = in->xf_count;
+                if (nlev > 1) {
+                    ray_level(in->lv[1], lo, ld);
+                    for (int k = 2; k < nlev; ++k) ray_level(sc.xinv[in->xf_first + k], lo, ld);
+                }
+                if (COUNT && mpos > first_mpos) n_inst++;   // the first one was counted by the analytic phase
+                const DMesh* mesh = sc.meshes + in->mesh;
+                rb = make_raybox(lo, ld);
+                float tin;
+                if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
+                    tm = HPT_INF; prim = -1; bu = 0.0f; bv = 0.0f; side = 0;
+                    tie_ok = (uint32_t)inst_idx < (h.inst_side & 0x7fffffffu);
+                    stk[0] = SENTINEL; sp = 1; ref = mesh->root_ref;
+                    break;
+                }
+                ++mpos;
+            }
+        }
+        if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+        // ---- traversal steps until enough lanes are done (all of them once the queue is empty)
+        const int keep_going_above = exhausted ? 0 : 64 - L.refill;
+        while (__popcll(__ballot(ref != SENTINEL)) > keep_going_above) {
+            if (ref >= 0) {
+                const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
+                const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+                if (COUNT) n_int++;
+                const float bound = fminf(tm, h.t);
+                float tinL, tinR;
+                const bool hitL = box_hit(rb, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound, tinL);
+                const bool hitR = box_hit(rb, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound, tinR);
+                const int l = __float_as_int(q0.w), r = __float_as_int(q1.w);
+                if (hitL && hitR) {
+                    const bool lfirst = tinL < tinR;
+                    stk[sp * HPT_BLOCK] = lfirst ? r : l;
+                    sp++;
+                    ref = lfirst ? l : r;
+                } else if (hitL) ref = l;
+                else if (hitR) ref = r;
+                else { --sp; ref = stk[sp * HPT_BLOCK]; }
+            } else if (ref != SENTINEL) {
+                const int tri = ~ref;
+                const float4* tq = tris + (uint32_t)tri * (uint32_t)HPT_TRI_QUADS;
+                const float4 a = tq[0], ab = tq[1], ac = tq[2];
+                if (COUNT) n_tri++;
+                float t, u, v; int s;
+                if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), lo, ld, t, u, v, s)) {
+                    // equal t inside a mesh: the lower triangle index wins (order-independent => deterministic; the
+                    // reference's "later visited wins" depends on its own tree, north_star excludes edge rays)
+                    if ((t < tm || (t == tm && tri < prim)) && (t < h.t || (tie_ok && t == h.t))) { tm = t; prim = tri; bu = u; bv = v; side = s; }
+                }
+                --sp;
+                ref = stk[sp * HPT_BLOCK];
+            }
+        }
+    }
+}
+
 // Closest hit over the rays of a (sharded) queue (scene.rs:190-208), workgroup-cooperative and persistent:
 //  phase 1 (all lanes, uniform control flow): every analytic instance (sphere / plane) in visiting order, plus the
 //          root-box test of the mesh instances; a ray that enters a mesh box is queued in LDS instead of traversed
@@ -317,16 +432,8 @@ template <bool COUNT>
 __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
                                                   const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                   unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
-    int* stk = L.stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    auto process_item = [&](uint4 it) {
-        const uint32_t i = it.x;
-        Hit h; h.t = __uint_as_float(it.z); h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = it.w;
-        trace_mesh_instances<COUNT>(sc, L, stk, xyz(ray_o[i]), xyz(ray_d[i]), (int)it.y, h, n_int, n_tri, n_inst);
-        hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
-        hit_inst[i] = h.inst_side;
-    };
-    if (threadIdx.x == 0) *L.qn = 0;
+    if (threadIdx.x == 0) { *L.qn = 0; *L.qhead = 0; }
     __syncthreads();
     const uint32_t total = work_items(wv);
     for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
@@ -349,18 +456,15 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
         }
         __syncthreads();
         const unsigned cnt = *L.qn;
-        const bool flush = cnt >= HPT_BLOCK;
-        if (flush) item = L.queue[cnt - HPT_BLOCK + threadIdx.x];
-        __syncthreads();
-        if (flush) {
-            if (threadIdx.x == 0) *L.qn = cnt - HPT_BLOCK;
-            process_item(item);
+        if (cnt > HPT_QUEUE_CAP - HPT_BLOCK) {      // the next chunk might not fit: drain everything (workgroup-uniform)
+            drain_queue<COUNT>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
+            __syncthreads();
+            if (threadIdx.x == 0) { *L.qn = 0; *L.qhead = 0; }
+            __syncthreads();
         }
-        __syncthreads();
     }
     const unsigned cnt = *L.qn;
-    for (unsigned start = 0; start < cnt; start += HPT_BLOCK)
-        if (start + threadIdx.x < cnt) process_item(L.queue[start + threadIdx.x]);
+    if (cnt) drain_queue<COUNT>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
 }
 
 template <typename T>
@@ -446,8 +550,9 @@ k_raygen(DScene sc, DPass ps) {
 // ------------------------------------------------------------------------------------------------ k_extend
 template <bool COUNT>
 __global__ void __launch_bounds__(HPT_BLOCK)
-k_extend(DScene sc, DPass ps, int depth, int stack_entries) {
+k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     Lds L = lds_carve(stack_entries);
+    L.refill = refill;
     lds_load_nodes(L, sc.nodes, sc.n_nodes);
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_SHARDS; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
@@ -855,7 +960,7 @@ static inline int grid_for(uint64_t n, int max_blocks) {
 }
 // dynamic LDS of the traversal kernels: stack + node cache + work queue + queue counter (see lds_carve)
 static inline size_t trav_lds_bytes(int stack_entries) {
-    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + HPT_QUEUE_CAP * sizeof(uint4) + 16;
+    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + HPT_QUEUE_CAP * sizeof(uint4) + 16;   // + qn, qhead
 }
 
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
@@ -875,10 +980,12 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
 }
+static int g_refill = 16;
+void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
     const size_t lds = trav_lds_bytes(stack_entries);
-    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries);
+    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
 }
 void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {
     const size_t tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);

@@ -43,6 +43,18 @@ def main():
             d.nodes = [n for n in d.nodes if n.geom != 3]; d.meshes = []
             for v in [int(c) for c in w[2:].split(",")]:
                 run("no teapot, variant %d" % v, d, variant=v)
+        elif w.startswith("R"):
+            for rep in range(2):
+                for r in [int(c) for c in w[1:].split(",")]:
+                    hpt.lib.hpt_debug_set_refill(r)
+                    run("refill %d (rep %d)" % (r, rep), d)
+            hpt.lib.hpt_debug_set_refill(16)
+        elif w.startswith("P"):
+            for rep in range(2):
+                for r in [int(c) for c in w[1:].split(",")]:
+                    hpt.lib.hpt_debug_set_park(r)
+                    run("park %d (rep %d)" % (r, rep), d)
+            hpt.lib.hpt_debug_set_park(24)
         elif w.startswith("B"):
             for b in [int(c) for c in w[1:].split(",")]:
                 run("blocks/CU %d" % b, d, bpc=b)
