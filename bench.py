@@ -72,9 +72,15 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render core has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # rehearsal hooks (never set by the driver): HPT_BENCH_BACKEND=gloo lets 2+ ranks share one GPU on a 1-GPU box
+    backend = os.environ.get("HPT_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import hpt
     from hpt import host_bvh, scene_io
@@ -82,7 +88,7 @@ def main():
 
     desc = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "scene.xml"))
     desc.camera.width, desc.camera.height = args.width, args.height
-    ctx = hpt.Context(local_rank)
+    ctx = hpt.Context(device_index)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
     tree = (lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if args.tree == "host" else None
@@ -98,8 +104,13 @@ def main():
         def step():
             st = scene.render_device(accum.data_ptr(), want_stats=True, spp=count, first_sample=first, max_depth=args.depth,
                                      seed=1, spp_per_pass=args.spp_per_pass, flags=flags)
-            if world > 1:
+            if world > 1 and backend == "nccl":
                 dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)     # RCCL sum-reduce of the float accumulators over xGMI
+            elif world > 1:                                         # rehearsal only: reduce through host memory
+                stream.synchronize()
+                host = accum.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                accum.copy_(host)
             if rank == 0:
                 torch.div(accum, float(args.spp), out=image)        # main.rs:110
             return st
@@ -122,7 +133,7 @@ def main():
         ext_s_local = sum(s.seconds_extend for s in stats)
         ext_launches = sum(s.launches_extend for s in stats)
         shade_s_local = sum(s.seconds_shade for s in stats)
-        vec = torch.tensor([elapsed, float(rays_local)], device="cuda", dtype=torch.float64)
+        vec = torch.tensor([elapsed, float(rays_local)], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         if world > 1:
             tmax = vec[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             rsum = vec[1:].clone(); dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
@@ -149,6 +160,7 @@ def main():
                        "spp_per_rank": count, "bvh": "reference bvh.rs tree built on host, tight refit" if args.tree == "host" else "library SAH",
                        "parallelism": "spp-split x%d + RCCL sum-reduce" % world},
             "samples_per_px_per_s": round(args.spp * args.steps / elapsed, 3),
+            "image_mean": [round(float(v), 6) for v in image.view(-1, 3).mean(dim=0).cpu()],
             "rays_per_step": rays_total / args.steps,
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": None,

@@ -611,11 +611,11 @@ struct EventLog {   // HPT_RENDER_TIME_KERNELS: (kind, start, stop) triples from
 };
 
 static int default_spp_per_pass(uint64_t npix, int want) {
-    if (want > 0) return want;
+    if (want > 0) return want > 64 ? 64 : want;
     const uint64_t target_paths = 8ull << 20;   // ~8M paths in flight per pass
     uint64_t s = target_paths / std::max<uint64_t>(npix, 1);
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 64) s = 64;   // the sample slot of a path travels in 6 bits next to its pixel index
     return (int)s;
 }
 
@@ -797,6 +797,7 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
             const int round = num_samples - have;
             uint64_t S = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)round, (8ull << 20) / n_active));
             if (p->spp_per_pass > 0) S = std::min<uint64_t>((uint64_t)p->spp_per_pass, (uint64_t)round);
+            S = std::min<uint64_t>(S, 64);
             CHK(ensure_pass_workspace(s, (uint64_t)n_active * S, ps));
             for (int done = 0; done < round; done += (int)S) {
                 const int cur = std::min<int>((int)S, round - done);

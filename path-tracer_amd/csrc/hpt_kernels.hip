@@ -531,7 +531,7 @@ k_raygen(DScene sc, DPass ps) {
         const uint32_t q = seg * ps.shard_cap + k * HPT_BLOCK + (path % HPT_BLOCK);
         ps.q[0].ray_o[q] = make_float4(eye.x, eye.y, eye.z, 1.0f);
         ps.q[0].ray_d[q] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(path));
-        ps.q[0].thr[q] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        ps.q[0].thr[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel | (s << 26)));   // pixel < 2^26, s < 64
         ps.radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0 && threadIdx.x < HPT_SHARDS) {
@@ -664,19 +664,20 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
     const DInstance& in = T.inst[inst_side & 0x7fffffffu];
     w.side = (int)(inst_side >> 31);
     w.material = in.material; w.node_id = in.node_id; w.prim_local = -1;
-    f3 lo = o, ld = d;
-    ray_level(in.lv[0], lo, ld);
-    if (in.xf_count > 1) {
-        ray_level(in.lv[1], lo, ld);
-        for (int k = 2; k < in.xf_count; ++k) ray_level(T.xinv[in.xf_first + k], lo, ld);
-    }
     f3 pos, normal, uv;
-    if (in.geom == 1) {
+    if (in.geom != 3) {   // sphere / plane: the local hit point comes from the local ray (geometry.rs:57,77)
+        f3 lo = o, ld = d;
+        ray_level(in.lv[0], lo, ld);
+        if (in.xf_count > 1) {
+            ray_level(in.lv[1], lo, ld);
+            for (int k = 2; k < in.xf_count; ++k) ray_level(T.xinv[in.xf_first + k], lo, ld);
+        }
         pos = add3(lo, scale3(ld, t));
+    }
+    if (in.geom == 1) {
         normal = normalize3(pos);
         uv = mk3(0.5f + atan2f(normal.y, normal.x) / (2.0f * PI_F), 0.5f - asinf(-normal.z) / PI_F, 0.0f);
     } else if (in.geom == 2) {
-        pos = add3(lo, scale3(ld, t));
         uv = mk3(0.5f + 0.5f * pos.x, 0.5f + 0.5f * pos.y, 0.0f);
         normal = mk3(0, 0, 1);
     } else {
@@ -772,8 +773,8 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
             const uint32_t path = __float_as_uint(d4.w);
             const f3 o = xyz(o4), d = xyz(d4), thr = xyz(thr4);
             const float weight = o4.w;
-            const uint32_t slot = path / ps.S, s = path - slot * ps.S;
-            const uint32_t pixel = ps.pixel_list ? ps.pixel_list[slot] : slot;
+            const uint32_t pix_s = __float_as_uint(thr4.w);
+            const uint32_t pixel = pix_s & 0x03ffffffu, s = pix_s >> 26;
             f3 add = mk3(0, 0, 0);
             bool have_add = false;
             if (inst_side == HPT_MISS_INST) {
@@ -841,7 +842,7 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                             const f3 np = add3(w.pos, scale3(new_dir, 0.01f));   // BIAS scene.rs:122
                             no = make_float4(np.x, np.y, np.z, weight * p);
                             nd = make_float4(new_dir.x, new_dir.y, new_dir.z, d4.w);
-                            nthr = make_float4(nt.x, nt.y, nt.z, 0.0f);
+                            nthr = make_float4(nt.x, nt.y, nt.z, thr4.w);
                             alive = true;
                         }
                     }
