@@ -426,7 +426,55 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
             }
         }
     }
-    if (inst.size() >= 0x7fffffffu) return fail(HPT_ERR_LIMIT, "too many instances");
+    if (inst.size() >= 0x3fffffffu) return fail(HPT_ERR_LIMIT, "too many instances");
+    if (tris.size() / 12 >= 0x40000000ull) return fail(HPT_ERR_LIMIT, "scene: more than 2^30 triangles");
+    // ---- TLAS over the instances' world boxes when the linear instance loop of scene.rs:193 would dominate
+    int tlas_min = 24;
+    if (const char* e = getenv("HPT_TLAS_MIN")) tlas_min = atoi(e);
+    int32_t use_tlas = 0, tlas_root = 0;
+    if ((int)inst.size() >= tlas_min && !inst.empty()) {
+        std::vector<float> wb(inst.size() * 6);
+        for (size_t i = 0; i < inst.size(); ++i) {
+            const DInstance& di = inst[i];
+            double lo[3], hi[3];
+            if (di.geom == HPT_GEOM_SPHERE) { for (int k = 0; k < 3; ++k) { lo[k] = -1; hi[k] = 1; } }
+            else if (di.geom == HPT_GEOM_PLANE) { lo[0] = lo[1] = -1; hi[0] = hi[1] = 1; lo[2] = hi[2] = 0; }
+            else { for (int k = 0; k < 3; ++k) { lo[k] = s->h_meshes[di.mesh].bmin[k]; hi[k] = s->h_meshes[di.mesh].bmax[k]; } }
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, scale = 0.0;
+            for (int c = 0; c < 8; ++c) {
+                double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+                for (int k = di.xf_count - 1; k >= 0; --k) {   // from_local through the chain, innermost first (scene.rs:282)
+                    const DXformFwd& X = xfwd[di.xf_first + k];
+                    const double q[3] = {X.m0[0] * p[0] + X.m0[1] * p[1] + X.m0[2] * p[2] + X.m0[3],
+                                         X.m1[0] * p[0] + X.m1[1] * p[1] + X.m1[2] * p[2] + X.m1[3],
+                                         X.m2[0] * p[0] + X.m2[1] * p[1] + X.m2[2] * p[2] + X.m2[3]};
+                    p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+                }
+                for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); scale = std::max(scale, std::fabs(p[k])); }
+            }
+            // conservative: the f32 chain of the kernels and this f64 evaluation differ by rounding
+            double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]});
+            const double pad = 1e-4 * ext + 1e-5 * scale + 1e-30;
+            for (int k = 0; k < 3; ++k) { wb[6 * i + k] = (float)(mn[k] - pad); wb[6 * i + 3 + k] = (float)(mx[k] + pad); }
+        }
+        HostTree tt; FlatMesh ft; std::string err;
+        tree_build_sah_boxes(wb.data(), (int32_t)inst.size(), tt);
+        if (!flatten_tree(tt, wb.data(), (int32_t)inst.size(), ft, err)) return fail(HPT_ERR_INVALID, "%s", err.c_str());
+        const int64_t node_base = (int64_t)(nodes.size() / 16);
+        if (node_base + ft.n_interior >= (1ll << 31)) return fail(HPT_ERR_LIMIT, "scene: more than 2^31 nodes");
+        auto rebase = [&](int32_t ref) -> int32_t { return ref >= 0 ? (int32_t)(ref + node_base) : ~(int32_t)(0x40000000 + (~ref)); };
+        for (int32_t i = 0; i < ft.n_interior; ++i) {
+            int32_t l, r;
+            std::memcpy(&l, &ft.nodes[(size_t)i * 16 + 3], 4); std::memcpy(&r, &ft.nodes[(size_t)i * 16 + 7], 4);
+            l = rebase(l); r = rebase(r);
+            std::memcpy(&ft.nodes[(size_t)i * 16 + 3], &l, 4); std::memcpy(&ft.nodes[(size_t)i * 16 + 7], &r, 4);
+        }
+        nodes.insert(nodes.end(), ft.nodes.begin(), ft.nodes.end());
+        use_tlas = 1; tlas_root = rebase(ft.root_ref);
+        // one stack: TLAS levels + the restore marker + the deepest BLAS + the bottom sentinel
+        s->stack_entries = ft.max_depth + 1 + s->stack_entries + 1;
+        if (s->stack_entries > 56) return fail(HPT_ERR_LIMIT, "two-level traversal needs %d stack entries (limit 56)", s->stack_entries);
+    }
     // ---- materials, images
     std::vector<DMaterial> mats(s->materials.size());
     for (size_t i = 0; i < mats.size(); ++i) {
@@ -453,6 +501,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     d.materials = s->d_materials.as<DMaterial>(); d.images = s->d_images.as<DImage>(); d.image_pool = s->d_pool.as<uint8_t>();
     d.n_instances = (int32_t)inst.size(); d.n_meshes = (int32_t)s->h_meshes.size();
     s->n_xf = (int)xinv.size(); s->n_mat = (int)mats.size();
+    d.use_tlas = use_tlas; d.tlas_root = tlas_root;
     d.n_mesh_instances = (int32_t)meshinst.size(); d.n_nodes = (int32_t)(nodes.size() / 16);
     conv_texture(s->background, d.background); conv_texture(s->environment, d.environment);
     camera_frame(s->camera, d.cam);

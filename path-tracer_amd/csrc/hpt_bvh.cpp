@@ -55,11 +55,20 @@ bool tree_from_reference_nodes(const hpt_bvh_node* nodes, int32_t nnodes, int32_
 }
 
 void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, HostTree& out) {
+    std::vector<float> b((size_t)ntri * 6);
+    for (int32_t i = 0; i < ntri; ++i) {
+        const Box x = tri_box(verts, tri_idx + 3 * (size_t)i);
+        for (int k = 0; k < 3; ++k) { b[6 * (size_t)i + k] = x.mn[k]; b[6 * (size_t)i + 3 + k] = x.mx[k]; }
+    }
+    tree_build_sah_boxes(b.data(), ntri, out);
+}
+
+void tree_build_sah_boxes(const float* leaf_boxes, int32_t ntri, HostTree& out) {
     const int NB = 16;
     std::vector<Box> boxes((size_t)ntri);
     std::vector<float> cent((size_t)ntri * 3);
     for (int32_t i = 0; i < ntri; ++i) {
-        boxes[i] = tri_box(verts, tri_idx + 3 * (size_t)i);
+        for (int k = 0; k < 3; ++k) { boxes[i].mn[k] = leaf_boxes[6 * (size_t)i + k]; boxes[i].mx[k] = leaf_boxes[6 * (size_t)i + 3 + k]; }
         for (int k = 0; k < 3; ++k) cent[3 * (size_t)i + k] = 0.5f * (boxes[i].mn[k] + boxes[i].mx[k]);
     }
     std::vector<int32_t> ids((size_t)ntri);
@@ -125,10 +134,9 @@ void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, H
     }
 }
 
-bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_idx, const float* normals, const uint32_t* nrm_idx,
-                  const float* uvw, const uint32_t* uv_idx, int32_t ntri, FlatMesh& out, std::string& err) {
+bool flatten_tree(const HostTree& tree, const float* leaf_boxes, int32_t nleaf, FlatMesh& out, std::string& err) {
     const int32_t nn = (int32_t)tree.left.size();
-    // post-order (children before parent) by reversing a pre-order walk
+    (void)nleaf;
     std::vector<int32_t> order; order.reserve(nn);
     {
         std::vector<int32_t> st{tree.root};
@@ -142,8 +150,10 @@ bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_
     std::vector<Box> box((size_t)nn);
     for (int32_t k = nn - 1; k >= 0; --k) {
         const int32_t i = order[k];
-        if (tree.prim[i] >= 0) box[i] = tri_box(verts, tri_idx + 3 * (size_t)tree.prim[i]);   // tight leaf box (bvh.rs:50-53)
-        else { box[i] = box[tree.left[i]]; box[i].grow(box[tree.right[i]]); }                 // tight refit (drops quirk 2)
+        if (tree.prim[i] >= 0) {   // tight leaf box (bvh.rs:50-53)
+            const float* b = leaf_boxes + 6 * (size_t)tree.prim[i];
+            for (int c = 0; c < 3; ++c) { box[i].mn[c] = b[c]; box[i].mx[c] = b[3 + c]; }
+        } else { box[i] = box[tree.left[i]]; box[i].grow(box[tree.right[i]]); }   // tight refit (drops quirk 2)
     }
     // breadth-first numbering of interior nodes + depth
     std::vector<int32_t> bfs_index((size_t)nn, -1), depth((size_t)nn, 0), queue;
@@ -169,6 +179,17 @@ bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_
         q[12] = R.mx[0]; q[13] = R.mx[1]; q[14] = R.mx[2];
     }
     for (int k = 0; k < 3; ++k) { out.bmin[k] = box[tree.root].mn[k]; out.bmax[k] = box[tree.root].mx[k]; }
+    return true;
+}
+
+bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_idx, const float* normals, const uint32_t* nrm_idx,
+                  const float* uvw, const uint32_t* uv_idx, int32_t ntri, FlatMesh& out, std::string& err) {
+    std::vector<float> leaf((size_t)ntri * 6);
+    for (int32_t f = 0; f < ntri; ++f) {
+        const Box x = tri_box(verts, tri_idx + 3 * (size_t)f);
+        for (int k = 0; k < 3; ++k) { leaf[6 * (size_t)f + k] = x.mn[k]; leaf[6 * (size_t)f + 3 + k] = x.mx[k]; }
+    }
+    if (!flatten_tree(tree, leaf.data(), ntri, out, err)) return false;
     out.tris.assign((size_t)ntri * 12, 0.0f);
     out.trishade.assign((size_t)ntri * 28, 0.0f);
     for (int32_t f = 0; f < ntri; ++f) {

@@ -25,6 +25,10 @@ struct FlatMesh {
 bool tree_from_reference_nodes(const hpt_bvh_node* nodes, int32_t nnodes, int32_t ntri, HostTree& out, std::string& err);
 // Binned SAH over triangle boxes/centroids (used when the host hands no tree, and for synthetic large scenes).
 void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, HostTree& out);
+// same over arbitrary leaf boxes (n x 6: min, max) -- the TLAS over instance world boxes uses this
+void tree_build_sah_boxes(const float* leaf_boxes, int32_t n, HostTree& out);
+// tight refit + breadth-first renumbering + Node64 packing of any tree over leaf boxes; leaf refs are ~prim
+bool flatten_tree(const HostTree& tree, const float* leaf_boxes, int32_t nleaf, FlatMesh& out, std::string& err);
 // Tight refit + breadth-first renumbering + packing.  Child refs are LOCAL to the mesh; the caller rebases them.
 bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_idx, const float* normals, const uint32_t* nrm_idx,
                   const float* uvw, const uint32_t* uv_idx, int32_t ntri, FlatMesh& out, std::string& err);

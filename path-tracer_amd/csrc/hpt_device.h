@@ -83,6 +83,7 @@ struct DScene {
     const DImage* images;
     const uint8_t* image_pool;
     int32_t n_instances, n_meshes, n_mesh_instances, n_nodes;
+    int32_t use_tlas, tlas_root;     // two-level traversal (many instances): ref of the TLAS root in nodes[]
     DTexture background, environment;
     DCamera cam;
 };

@@ -211,7 +211,7 @@ __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, 
 struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 
 // ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
-//   [stack: stack_entries x HPT_BLOCK ints][node cache: 4 planes x HPT_NODE_CACHE float4][queue: HPT_QUEUE_CAP uint4][qn]
+//   [stack: stack_entries x HPT_BLOCK ints][node cache: 4 planes x HPT_NODE_CACHE float4][qn, qhead][queue: HPT_QUEUE_CAP uint4]
 struct Lds {
     int* stack; float4* ncache; uint4* queue; unsigned* qn; unsigned* qhead; int n_cached; int refill;
 };
@@ -220,9 +220,9 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     Lds L;
     L.stack = (int*)lds_raw;
     L.ncache = (float4*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
-    L.queue = (uint4*)(L.ncache + 4 * HPT_NODE_CACHE);
-    L.qn = (unsigned*)(L.queue + HPT_QUEUE_CAP);
+    L.qn = (unsigned*)(L.ncache + 4 * HPT_NODE_CACHE);
     L.qhead = L.qn + 1;
+    L.queue = (uint4*)(L.qn + 4);      // the two-level (TLAS) path launches without the queue
     L.n_cached = 0; L.refill = 16;
     return L;
 }
@@ -467,6 +467,142 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     if (cnt) drain_queue<COUNT>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
 }
 
+// ------------------------------------------------------------------------------------------------ two-level traversal
+// Scenes with many instances (Scene::intersect is linear in the top-level nodes -- fatal for 10 k spheres
+// or 3 k mesh instances) get a TLAS: a BVH2 over the instances' world boxes, stored as Node64 records behind the mesh
+// nodes, whose leaf refs are ~(HPT_INST_BASE + instance).  One lane owns one ray and walks TLAS and BLAS with a single
+// LDS stack; entering a mesh instance pushes HPT_REF_RESTORE, which brings the world-space ray back when popped.
+// Hits are order-independent: candidate (t, instance, triangle) replaces the best one iff it is lexicographically
+// smaller, which is the reference's rule "strictly nearer wins, earlier node wins ties" (scene.rs:196,251).
+#define HPT_INST_BASE 0x40000000
+#define HPT_REF_RESTORE ((int)~0x7ffffffe)
+template <bool COUNT>
+__device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, uint32_t base_slot, uint32_t n_valid,
+                                                const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
+                                                unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    int* stk = L.stack + threadIdx.x;
+    const int SENTINEL = (int)0x80000000;
+    const float4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ tris = sc.tris;
+    bool have = false, exhausted = false;
+    uint32_t slot = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), co = o, cd = d;
+    Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+    RayBox rb = make_raybox(o, d);
+    int ref = SENTINEL, sp = 1; uint32_t cur_inst = 0;
+    for (;;) {
+        if (have && ref == SENTINEL) {   // ray finished
+            hit[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+            hit_inst[slot] = h.inst_side;
+            have = false;
+        }
+        if (!exhausted) {
+            bool tried = false;
+            if (!have) {
+                tried = true;
+                const unsigned idx = atomicAdd(L.qhead, 1u);
+                if (idx < n_valid) {
+                    slot = base_slot + idx;
+                    o = xyz(ray_o[slot]); d = xyz(ray_d[slot]); co = o; cd = d;
+                    rb = make_raybox(o, d);
+                    h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+                    stk[0] = SENTINEL; sp = 1; ref = sc.tlas_root;
+                    have = true;
+                }
+            }
+            exhausted = __ballot(tried && !have) != 0ull;
+        }
+        if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+        const int keep_going_above = exhausted ? 0 : 64 - L.refill;
+        while (__popcll(__ballot(have && ref != SENTINEL)) > keep_going_above) {
+            if (!have) continue;
+            if (ref >= 0) {
+                const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
+                const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+                if (COUNT) n_int++;
+                float tinL, tinR;
+                const bool hitL = box_hit(rb, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), h.t, tinL);
+                const bool hitR = box_hit(rb, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), h.t, tinR);
+                const int l = __float_as_int(q0.w), r = __float_as_int(q1.w);
+                if (hitL && hitR) {
+                    const bool lfirst = tinL < tinR;
+                    stk[sp * HPT_BLOCK] = lfirst ? r : l;
+                    sp++;
+                    ref = lfirst ? l : r;
+                } else if (hitL) ref = l;
+                else if (hitR) ref = r;
+                else { --sp; ref = stk[sp * HPT_BLOCK]; }
+            } else if (ref != SENTINEL) {
+                const uint32_t x = (uint32_t)~ref;
+                if (x < (uint32_t)HPT_INST_BASE) {            // triangle of the mesh instance being walked
+                    const float4* tq = tris + x * (uint32_t)HPT_TRI_QUADS;
+                    const float4 a = tq[0], ab = tq[1], ac = tq[2];
+                    if (COUNT) n_tri++;
+                    float t, u, v; int s;
+                    if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), co, cd, t, u, v, s)) {
+                        const uint32_t bi = h.inst_side & 0x7fffffffu;
+                        if (t < h.t || (t == h.t && (cur_inst < bi || (cur_inst == bi && (int)x < h.prim)))) {
+                            h.t = t; h.u = u; h.v = v; h.prim = (int)x; h.inst_side = cur_inst | ((uint32_t)s << 31);
+                        }
+                    }
+                } else if (ref == HPT_REF_RESTORE) {          // back from a mesh instance to the world-space ray
+                    co = o; cd = d; rb = make_raybox(o, d);
+                } else {                                      // TLAS leaf: an instance
+                    const uint32_t i = x - (uint32_t)HPT_INST_BASE;
+                    const DInstance* in = sc.instances + i;
+                    f3 lo = o, ld = d;
+                    ray_level(in->lv[0], lo, ld);
+                    const int nlev = in->xf_count;
+                    if (nlev > 1) {
+                        ray_level(in->lv[1], lo, ld);
+                        for (int k = 2; k < nlev; ++k) ray_level(sc.xinv[in->xf_first + k], lo, ld);
+                    }
+                    if (COUNT) n_inst++;
+                    const int geom = in->geom;
+                    if (geom == 3) {
+                        const DMesh* mesh = sc.meshes + in->mesh;
+                        const RayBox lrb = make_raybox(lo, ld);
+                        float tin;
+                        if (box_hit(lrb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
+                            co = lo; cd = ld; rb = lrb; cur_inst = i;
+                            stk[sp * HPT_BLOCK] = HPT_REF_RESTORE;
+                            sp++;
+                            ref = mesh->root_ref;
+                            continue;
+                        }
+                    } else {
+                        float t; int s;
+                        const bool ok = geom == 1 ? intersect_sphere(lo, ld, t, s) : intersect_plane(lo, ld, t, s);
+                        if (ok && (t < h.t || (t == h.t && i < (h.inst_side & 0x7fffffffu)))) { h.t = t; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = i | ((uint32_t)s << 31); }
+                    }
+                }
+                --sp;
+                ref = stk[sp * HPT_BLOCK];
+            }
+        }
+    }
+}
+
+// closest hit over a (sharded) queue through the TLAS: a workgroup takes groups of 4 chunks (1024 slots) so that lanes
+// that finish early find more rays to pull
+template <bool COUNT>
+__device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
+                                                       const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
+                                                       unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    const uint32_t GROUP = 4 * HPT_BLOCK;
+    const uint32_t groups_per_seg = (wv.cap + GROUP - 1) / GROUP, total = wv.shards * groups_per_seg;
+    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const uint32_t s = w % wv.shards, g = w / wv.shards;
+        const uint32_t cnt = wv.counts ? wv.counts[s] : wv.n_linear;
+        const uint32_t first = g * GROUP;
+        if (threadIdx.x == 0) *L.qhead = 0;
+        __syncthreads();
+        if (first < cnt) drain_rays_tlas<COUNT>(sc, L, s * wv.cap + first, min(GROUP, cnt - first), ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -557,7 +693,8 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_SHARDS; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
-    block_closest_hit<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    if (sc.use_tlas) block_closest_hit_tlas<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    else block_closest_hit<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
                            c = wave_sum<unsigned long long>(n_inst);
@@ -707,7 +844,8 @@ k_scene_closest(DScene sc, long long n, const float4* __restrict__ org, const fl
     unsigned c0 = 0, c1 = 0, c2 = 0;
     WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n;
     wv.cap = (uint32_t)((n + HPT_BLOCK - 1) / HPT_BLOCK) * HPT_BLOCK;
-    block_closest_hit<false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2);
+    if (sc.use_tlas) block_closest_hit_tlas<false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2);
+    else block_closest_hit<false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2);
 }
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_scene_hitinfo(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
@@ -960,8 +1098,8 @@ static inline int grid_for(uint64_t n, int max_blocks) {
     return (int)b;
 }
 // dynamic LDS of the traversal kernels: stack + node cache + work queue + queue counter (see lds_carve)
-static inline size_t trav_lds_bytes(int stack_entries) {
-    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + HPT_QUEUE_CAP * sizeof(uint4) + 16;   // + qn, qhead
+static inline size_t trav_lds_bytes(int stack_entries, bool with_queue = true) {
+    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + 16 + (with_queue ? HPT_QUEUE_CAP * sizeof(uint4) : 0);
 }
 
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
@@ -975,7 +1113,7 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
                           float4* pos, float4* normal, float4* uvw) {
     const int grid = grid_for((uint64_t)n, max_blocks);
-    hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries), st, sc, n, org, dir, hit, hit_inst, stack_entries);
+    hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries, !sc.use_tlas), st, sc, n, org, dir, hit, hit_inst, stack_entries);
     hipLaunchKernelGGL(k_scene_hitinfo, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, node, prim, t, side, pos, normal, uvw);
 }
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
@@ -984,7 +1122,7 @@ void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& 
 static int g_refill = 16;
 void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
-    const size_t lds = trav_lds_bytes(stack_entries);
+    const size_t lds = trav_lds_bytes(stack_entries, !sc.use_tlas);
     if (count) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
     else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
 }

@@ -1,0 +1,81 @@
+"""BASELINE.json configs 3-5 at test size: library-built SAH BLAS, TLAS over many instances, divergence-heavy sphere
+scene -- hit records bit-exact against the oracle's linear Scene::intersect, images at matched spp and RNG."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scenes
+from conftest import host_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def camera_and_random_rays(osc, desc, n, seed):
+    rng = np.random.default_rng(seed)
+    cam = desc.camera
+    pr = [osc.primary_ray(int(x), int(y), 1 + int(k), 1) for x, y, k in zip(rng.integers(0, cam.width, n // 2), rng.integers(0, cam.height, n // 2), rng.integers(0, 8, n // 2))]
+    o = np.array([p[0] for p in pr], np.float32); d = np.array([p[1] for p in pr], np.float32)
+    # bounce-like rays: start at primary hits, random directions
+    h = osc.intersect(o, d)
+    ok = h["node"] >= 0
+    o2 = (h["pos"][ok] + 0.01 * h["normal"][ok]).astype(np.float32)
+    d2 = rng.normal(size=o2.shape); d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+    return np.concatenate([o, o2]), np.concatenate([d, d2])
+
+
+def check_scene(ctx, olib, desc, n_rays, spp, depth, host_bvh=None, img_tol=2e-3):
+    import hpt
+    osc = ol.OracleScene(olib, desc)
+    gsc = hpt.Scene(ctx, desc, host_bvh=host_bvh)
+    o, d = camera_and_random_rays(osc, desc, n_rays, 5)
+    g = gsc.intersect(o, d); r = osc.intersect(o, d)
+    same_node = g["node"] == r["node"]
+    # equal-t ties between different objects are resolved by node order on both sides; inside a mesh the tie winner
+    # depends on the tree (edge rays, excluded by north_star): compare ids where t differs from every neighbour
+    assert same_node.mean() > 0.9999, same_node.mean()
+    np.testing.assert_array_equal(g["t"][same_node], r["t"][same_node])
+    np.testing.assert_array_equal(g["side"][same_node], r["side"][same_node])
+    same_prim = same_node & (g["prim"] == r["prim"])
+    assert same_prim.sum() >= same_node.sum() - max(3, n_rays // 20000)
+    np.testing.assert_array_equal(g["pos"][same_prim], r["pos"][same_prim])
+    np.testing.assert_array_equal(g["normal"][same_prim], r["normal"][same_prim])
+    ref = osc.render(spp=spp, max_depth=depth, seed=1)
+    img = gsc.render(spp=spp, max_depth=depth, seed=1)
+    nr = img["stats"].rays_primary + img["stats"].rays_bounce
+    assert abs(nr - ref["stats"].rays) <= max(20, ref["stats"].rays // 20000)
+    rel = float(np.sqrt(((img["rgb"] - ref["rgb"]) ** 2).mean()) / ref["rgb"].mean())
+    assert rel <= img_tol, rel
+    gsc.close()
+    return (r["node"] >= 0).mean()
+
+
+def test_config3_soup(ctx, olib):
+    desc = scenes.soup(20000)
+    hit_rate = check_scene(ctx, olib, desc, 20000, spp=4, depth=8)
+    assert hit_rate > 0.3
+
+
+def test_config4_instanced_tlas(ctx, olib, desc):
+    d = scenes.instanced(desc.meshes[0], 4)        # 64 teapot instances + floor: TLAS path (>= 24 instances)
+    check_scene(ctx, olib, d, 20000, spp=2, depth=4, host_bvh=host_tree)
+
+
+def test_config5_spheres_tlas(ctx, olib):
+    d = scenes.spheres(2000)
+    check_scene(ctx, olib, d, 20000, spp=4, depth=16, img_tol=5e-3)
+
+
+def test_tlas_equals_linear(ctx, olib, desc, monkeypatch):
+    """the same scene through the linear instance loop and through the TLAS gives identical hit records"""
+    import hpt
+    d = scenes.spheres(300)
+    osc = ol.OracleScene(olib, d)
+    o, dd = camera_and_random_rays(osc, d, 8000, 9)
+    monkeypatch.setenv("HPT_TLAS_MIN", "1000000")
+    lin = hpt.Scene(ctx, d)
+    monkeypatch.setenv("HPT_TLAS_MIN", "2")
+    tl = hpt.Scene(ctx, d)
+    a, b = lin.intersect(o, dd), tl.intersect(o, dd)
+    for k in ("node", "prim", "t", "side", "pos", "normal"):
+        np.testing.assert_array_equal(a[k], b[k])
+    lin.close(); tl.close()
