@@ -33,6 +33,21 @@ HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s sp
 EXTEND_QUEUE_BYTES = 52    # per ray in k_extend itself: ray_o + ray_d read (32 B), hit + hit_inst written (20 B)
 
 
+def recorded_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share
+    a pass, and counters cannot be read from inside this process): the newest profiles/*_pmc_traffic.json written by
+    scripts/gpu_profile.sh for this same workload (same passes of 4 spp -> same launches).  None if absent."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            rec = json.load(open(f))
+            best = (int(rec[kernel]["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT))
+        except Exception:
+            continue
+    return best
+
+
 def cpu_baseline(desc, spp, depth, seed):
     """The oracle (kind "port": C restatement of the reference's algorithm, faithful mode -- reference tree with loose
     boxes, no pruning, per-call matrix inversion) timed on a bounded sample of the same workload."""
@@ -142,16 +157,21 @@ def main():
             rays_total = float(rays_local)
 
         # per-ray algorithmic bytes of k_extend from an instrumented (counters on), untimed run of the same kernel on
-        # a slice of this rank's samples: 64 B per interior node popped + 48 B per triangle tested + 64 B per instance
-        # record entered + the queue bytes the kernel itself moves (DESIGN.md "Roofline")
+        # a slice of this rank's samples: 64 B per interior node popped + 48 B per triangle tested + the queue bytes the
+        # kernel itself moves (DESIGN.md "Roofline").  Instance records (128 B) count per ray only when rays reach them
+        # one by one through the TLAS; the linear instance loop of small scenes reads each record once per WORKGROUP
+        # (wave-uniform loads), which is < 0.1 % of the bytes and left out.
         cst = scene.render_device(accum.data_ptr(), want_stats=True, spp=min(count, 4), first_sample=first, max_depth=args.depth, seed=1,
                                   spp_per_pass=args.spp_per_pass, flags=hpt.RENDER_COUNTERS)
         crays = cst.rays_primary + cst.rays_bounce
-        bytes_per_ray = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested + 64.0 * cst.inst_tests) / crays + EXTEND_QUEUE_BYTES
+        info = scene.info()
+        inst_bytes = 128.0 * cst.inst_tests if info.uses_tlas else 0.0
+        bytes_per_ray = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested + inst_bytes) / crays + EXTEND_QUEUE_BYTES
         bvh_bytes_per_ray = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested) / crays
 
     if rank == 0:
         achieved = bytes_per_ray * rays_local / ext_s_local
+        traffic = recorded_traffic("k_extend") if (args.width, args.height, args.depth, args.tree) == (1920, 1080, 8, "host") else None
         line = {
             "metric": "Mrays/sec (primary+bounce), teapot 1080p", "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -163,8 +183,11 @@ def main():
             "image_mean": [round(float(v), 6) for v in image.view(-1, 3).mean(dim=0).cpu()],
             "rays_per_step": rays_total / args.steps,
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None, "algorithmic_bytes_per_launch": int(bytes_per_ray * rays_local / max(ext_launches, 1)),
                          "bytes_per_ray": round(bytes_per_ray, 1), "bvh_bytes_per_ray": round(bvh_bytes_per_ray, 1),
+                         "nodes_per_ray": round(cst.nodes_visited / crays, 3), "tris_per_ray": round(cst.tris_tested / crays, 3),
+                         "scene_bytes_in_hbm": int(info.device_bytes),
                          "bvh_fetch_frac": round(bvh_bytes_per_ray * rays_local / ext_s_local / HBM_PEAK, 4),
                          "avg_launch_ms": round(ext_s_local / max(ext_launches, 1) * 1e3, 4), "launches": int(ext_launches),
                          "extend_share_of_step": round(ext_s_local / (elapsed), 3), "shade_share_of_step": round(shade_s_local / elapsed, 3)},

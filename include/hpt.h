@@ -107,6 +107,15 @@ typedef struct {
     double seconds_total;      /* incl. H2D/D2H copies for the host-pointer entry */
 } hpt_trace_stats;
 
+typedef struct {               /* what hpt_scene_commit laid out in HBM */
+    int32_t n_instances, n_mesh_instances, n_meshes, n_materials;
+    int32_t n_nodes;           /* Node64 records, all BLASes + the TLAS */
+    int32_t tlas_nodes;        /* of which TLAS (0 when the instance list is walked linearly, scene.rs:193) */
+    int32_t uses_tlas, stack_entries;
+    int64_t n_triangles;
+    uint64_t device_bytes;     /* scene data resident in HBM (render workspaces excluded) */
+} hpt_scene_info_t;
+
 /* ---- misc ---- */
 const char* hpt_version(void);
 const char* hpt_last_error(void);
@@ -152,6 +161,7 @@ int hpt_scene_set_environment(hpt_scene* scene, const hpt_texture* tex);    /* S
 int hpt_scene_set_camera(hpt_scene* scene, const hpt_camera* cam);          /* Camera (scene.rs:76) */
 /* flatten + upload (replicated per GPU: every rank commits the same scene) */
 int hpt_scene_commit(hpt_scene* scene);
+int hpt_scene_info(hpt_scene* scene, hpt_scene_info_t* out);   /* no counterpart in the reference: sizes for logs and roofline accounting */
 
 /* ---- parity entry: Mesh::intersect (geometry.rs:132-158) over n local-space rays against one mesh ----
  * prim = -1 on miss (t,u,v = 0); side: 1 = Side::Front, 0 = Side::Back.  Host pointers; outputs caller-allocated. */
@@ -179,6 +189,20 @@ int hpt_render(hpt_scene* scene, const hpt_render_params* params, float* rgb, ui
  * context stream before returning only if stats != NULL. */
 int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
                       hpt_render_stats* stats);
+/* One round of the adaptive loop (main.rs:72-99 restricted to a sample range) on DEVICE buffers, for hosts that
+ * drive the rounds themselves -- a rank of a multi-GPU adaptive render renders its share of the round's samples and
+ * all-reduces the min/max planes before the contrast test.  params: adaptive = 0, first_sample, spp =
+ * this call's sample range; pixel_list (device, n_pixels entries; NULL = every pixel in order) = the pixels still
+ * active.  rgb_sum (W*H*3) is ADDED to; minmax (W*H*6: per pixel min r,g,b then max r,g,b; the caller initialises
+ * min = +inf, max = 0 as main.rs:90-92) is folded into; NULL skips it. */
+int hpt_render_round_device(hpt_scene* scene, const hpt_render_params* params, const uint32_t* pixel_list_device,
+                            uint32_t n_pixels, float* rgb_sum_device, float* minmax_device, hpt_render_stats* stats);
+/* The contrast test of main.rs:101-106 on DEVICE buffers: list_out receives those pixels of list_in (NULL = all)
+ * with (max-min)/(min+max) above a threshold in any channel, their samples_per_px entry is set to next_num_samples,
+ * *n_out (host) = how many.  The order of list_out is unspecified (results do not depend on it).  Synchronises. */
+int hpt_adaptive_select_device(hpt_scene* scene, const uint32_t* list_in_device, uint32_t n_in, const float* minmax_device,
+                               const float thresholds[3], uint32_t* list_out_device, uint32_t* samples_per_px_device,
+                               uint32_t next_num_samples, uint32_t* n_out);
 /* optional per-sample radiance dump for parity tests (fixed mode): per_sample = W*H*spp*3 floats on the HOST,
  * pixel-major then sample. */
 int hpt_render_samples(hpt_scene* scene, const hpt_render_params* params, float* per_sample);

@@ -91,6 +91,7 @@ struct hpt_scene {
     DScene ds;
     int stack_entries = 1;
     int n_xf = 0, n_mat = 0;
+    int32_t tlas_nodes = 0; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
     DevBuf w_q[2][3], w_hit, w_hit_inst, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
     // trace workspace
@@ -432,6 +433,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     int tlas_min = 24;
     if (const char* e = getenv("HPT_TLAS_MIN")) tlas_min = atoi(e);
     int32_t use_tlas = 0, tlas_root = 0;
+    s->tlas_nodes = 0;
     if ((int)inst.size() >= tlas_min && !inst.empty()) {
         std::vector<float> wb(inst.size() * 6);
         for (size_t i = 0; i < inst.size(); ++i) {
@@ -470,7 +472,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
             std::memcpy(&ft.nodes[(size_t)i * 16 + 3], &l, 4); std::memcpy(&ft.nodes[(size_t)i * 16 + 7], &r, 4);
         }
         nodes.insert(nodes.end(), ft.nodes.begin(), ft.nodes.end());
-        use_tlas = 1; tlas_root = rebase(ft.root_ref);
+        use_tlas = 1; tlas_root = rebase(ft.root_ref); s->tlas_nodes = ft.n_interior;
         // one stack: TLAS levels + the restore marker + the deepest BLAS + the bottom sentinel
         s->stack_entries = ft.max_depth + 1 + s->stack_entries + 1;
         if (s->stack_entries > 56) return fail(HPT_ERR_LIMIT, "two-level traversal needs %d stack entries (limit 56)", s->stack_entries);
@@ -501,6 +503,9 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     d.materials = s->d_materials.as<DMaterial>(); d.images = s->d_images.as<DImage>(); d.image_pool = s->d_pool.as<uint8_t>();
     d.n_instances = (int32_t)inst.size(); d.n_meshes = (int32_t)s->h_meshes.size();
     s->n_xf = (int)xinv.size(); s->n_mat = (int)mats.size();
+    s->n_tris_total = (int64_t)(tris.size() / 12);
+    s->device_bytes = nodes.size() * 4 + tris.size() * 4 + trishade.size() * 4 + inst.size() * sizeof(DInstance) + xinv.size() * sizeof(DXformInv) +
+                      xfwd.size() * sizeof(DXformFwd) + mats.size() * sizeof(DMaterial) + pool.size();
     d.use_tlas = use_tlas; d.tlas_root = tlas_root;
     d.n_mesh_instances = (int32_t)meshinst.size(); d.n_nodes = (int32_t)(nodes.size() / 16);
     conv_texture(s->background, d.background); conv_texture(s->environment, d.environment);
@@ -720,11 +725,15 @@ static int check_params(hpt_scene* s, const hpt_render_params* p) {
     return HPT_OK;
 }
 
-// Fixed-spp render of samples first_sample+1 ..= first_sample+spp into accum (device, W*H*3, ADDED in sample order).
-static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, float* per_sample_host, hpt_render_stats* stats, EventLog& ev) {
+// Render of samples first_sample+1 ..= first_sample+spp of the n_active pixels in pixel_list (device; NULL = every
+// pixel, n_active = W*H) into accum (device, W*H*3, ADDED in sample order) and, when minmax != NULL, folded into the
+// per-channel running min/max of main.rs:90-100.
+static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t* pixel_list, uint32_t n_active, float* accum, float* minmax,
+                        float* per_sample_host, hpt_render_stats* stats, EventLog& ev) {
     hpt_context* ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    const uint64_t npix = n_active;
+    if (npix == 0) return HPT_OK;
     const int S = std::min(default_spp_per_pass(npix, p->spp_per_pass), p->spp);
     DPass ps; std::memset(&ps, 0, sizeof ps);
     CHK(ensure_pass_workspace(s, npix * (uint64_t)S, ps));
@@ -737,10 +746,10 @@ static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, 
     for (int done = 0; done < p->spp; done += S) {
         const int cur = std::min(S, p->spp - done);
         ps.halton = s->w_halton.as<float2>() + done;
-        ps.pixel_list = nullptr; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
+        ps.pixel_list = pixel_list; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
         ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
         ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
-        CHK(run_pass(s, ps, accum, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->extend_blocks));
+        CHK(run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->extend_blocks));
         ++passes;
         if (per_sample_host) {
             rad.resize((size_t)npix * cur * 4);
@@ -753,6 +762,10 @@ static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, 
     }
     if (stats) { stats->passes += passes; stats->samples += npix * (uint64_t)p->spp; }
     return HPT_OK;
+}
+
+static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, float* per_sample_host, hpt_render_stats* stats, EventLog& ev) {
+    return render_range(s, p, nullptr, (uint32_t)((uint64_t)s->ds.cam.w * s->ds.cam.h), accum, nullptr, per_sample_host, stats, ev);
 }
 
 static int finish_stats(hpt_scene* s, hpt_render_stats* stats, EventLog& ev, double t0) {
@@ -834,29 +847,12 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
             HIPCHK(hipStreamSynchronize(st));
         }
         hptk_fill_u32(st, ctx->max_blocks, s->w_spp.as<uint32_t>(), npix, (uint32_t)p->initial_samples);
-        const int max_round = p->max_samples;
-        std::vector<float> hal((size_t)max_round * 2);
-        for (int k = 0; k < max_round; ++k) { hal[2 * k] = hpt_halton(k + 1, 2); hal[2 * k + 1] = hpt_halton(k + 1, 3); }
-        CHK(upload(s->w_halton, hal, st));
-        HIPCHK(hipStreamSynchronize(st));
         int have = 0, num_samples = p->initial_samples, cur_list = -1;   // -1: all pixels
         uint32_t n_active = (uint32_t)npix;
-        DPass ps; std::memset(&ps, 0, sizeof ps);
         while (n_active > 0) {
-            const int round = num_samples - have;
-            uint64_t S = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)round, (8ull << 20) / n_active));
-            if (p->spp_per_pass > 0) S = std::min<uint64_t>((uint64_t)p->spp_per_pass, (uint64_t)round);
-            S = std::min<uint64_t>(S, 64);
-            CHK(ensure_pass_workspace(s, (uint64_t)n_active * S, ps));
-            for (int done = 0; done < round; done += (int)S) {
-                const int cur = std::min<int>((int)S, round - done);
-                ps.halton = s->w_halton.as<float2>() + have + done;
-                ps.pixel_list = cur_list < 0 ? nullptr : s->w_list[cur_list].as<uint32_t>();
-                ps.n_slots = n_active; ps.S = (uint32_t)cur; ps.first_sample = (uint32_t)(have + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
-                ps.shard_cap = shard_cap_for((uint64_t)n_active * cur);
-                CHK(run_pass(s, ps, accum, s->w_minmax.as<float>(), (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->extend_blocks));
-                if (stats) { stats->passes++; stats->samples += (uint64_t)n_active * cur; }
-            }
+            hpt_render_params rp = *p;   // this round: samples (have, num_samples] of the still-active pixels
+            rp.adaptive = 0; rp.first_sample = have; rp.spp = num_samples - have;
+            CHK(render_range(s, &rp, cur_list < 0 ? nullptr : s->w_list[cur_list].as<uint32_t>(), n_active, accum, s->w_minmax.as<float>(), nullptr, stats, ev));
             have = num_samples;
             if (num_samples >= p->max_samples) break;   // main.rs:101 first clause
             const int next = cur_list < 0 ? 0 : 1 - cur_list;
@@ -877,6 +873,63 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpy(rgb, s->w_out.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (stats) return finish_stats(s, stats, ev, t0);
+    return HPT_OK;
+}
+
+// One round of the adaptive loop with DEVICE buffers, for hosts that drive the rounds themselves (one rank of a
+// multi-GPU adaptive render: the min/max planes are all-reduced between rounds, hpt/dist.py).
+extern "C" int hpt_render_round_device(hpt_scene* s, const hpt_render_params* p, const uint32_t* pixel_list_device, uint32_t n_pixels,
+                                       float* rgb_sum_device, float* minmax_device, hpt_render_stats* stats) {
+    CHK(check_params(s, p));
+    if (p->adaptive) return fail(HPT_ERR_INVALID, "hpt_render_round_device: params describe ONE round (adaptive = 0, first_sample, spp)");
+    if (!rgb_sum_device) return fail(HPT_ERR_INVALID, "hpt_render_round_device: null accumulator");
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    if (!pixel_list_device) n_pixels = (uint32_t)npix;
+    if (n_pixels > npix) return fail(HPT_ERR_INVALID, "hpt_render_round_device: %u listed pixels, image has %llu", n_pixels, (unsigned long long)npix);
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const double t0 = now_s();
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    EventLog ev{ctx, stats && (p->flags & HPT_RENDER_TIME_KERNELS)};
+    CHK(render_range(s, p, pixel_list_device, n_pixels, rgb_sum_device, minmax_device, nullptr, stats, ev));
+    if (stats) { stats->samples = (uint64_t)n_pixels * (uint64_t)p->spp; }
+    return finish_stats(s, stats, ev, t0);
+}
+
+// main.rs:101-106 on DEVICE buffers: which of the listed pixels go on to the next round.
+extern "C" int hpt_adaptive_select_device(hpt_scene* s, const uint32_t* list_in_device, uint32_t n_in, const float* minmax_device,
+                                          const float thresholds[3], uint32_t* list_out_device, uint32_t* samples_per_px_device,
+                                          uint32_t next_num_samples, uint32_t* n_out) {
+    CHK(need_committed(s));
+    if (!minmax_device || !thresholds || !list_out_device || !samples_per_px_device || !n_out) return fail(HPT_ERR_INVALID, "hpt_adaptive_select_device: null argument");
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    if (!list_in_device) n_in = (uint32_t)npix;
+    if (n_in > npix) return fail(HPT_ERR_INVALID, "hpt_adaptive_select_device: %u listed pixels, image has %llu", n_in, (unsigned long long)npix);
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    *n_out = 0;
+    if (n_in == 0) return HPT_OK;
+    CHK(s->w_listcount.ensure(sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(s->w_listcount.p, 0, sizeof(uint32_t), st));
+    hptk_adaptive_select(st, ctx->max_blocks, list_in_device, n_in, minmax_device, thresholds, list_out_device, s->w_listcount.as<uint32_t>(),
+                         samples_per_px_device, next_num_samples);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(n_out, s->w_listcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HPT_OK;
+}
+
+extern "C" int hpt_scene_info(hpt_scene* s, hpt_scene_info_t* out) {
+    CHK(need_committed(s));
+    if (!out) return fail(HPT_ERR_INVALID, "hpt_scene_info: null output");
+    std::memset(out, 0, sizeof *out);
+    out->n_instances = (int32_t)s->ds.n_instances; out->n_mesh_instances = (int32_t)s->ds.n_mesh_instances;
+    out->n_meshes = (int32_t)s->meshes.size(); out->n_materials = s->n_mat;
+    out->n_nodes = s->ds.n_nodes; out->n_triangles = s->n_tris_total; out->tlas_nodes = s->tlas_nodes;
+    out->uses_tlas = s->ds.use_tlas; out->stack_entries = s->stack_entries; out->device_bytes = s->device_bytes;
     return HPT_OK;
 }
 

@@ -58,6 +58,12 @@ class TraceStats(C.Structure):
                 ("seconds_kernel", C.c_double), ("seconds_total", C.c_double)]
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [("n_instances", C.c_int32), ("n_mesh_instances", C.c_int32), ("n_meshes", C.c_int32), ("n_materials", C.c_int32),
+                ("n_nodes", C.c_int32), ("tlas_nodes", C.c_int32), ("uses_tlas", C.c_int32), ("stack_entries", C.c_int32),
+                ("n_triangles", C.c_int64), ("device_bytes", C.c_uint64)]
+
+
 # every symbol include/hpt.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hpt_version", "hpt_last_error", "hpt_device_count", "hpt_rng_f32", "hpt_halton", "hpt_tonemap_rgba8",
@@ -65,6 +71,7 @@ EXPORTS = [
     "hpt_scene_create", "hpt_scene_destroy", "hpt_scene_add_mesh", "hpt_scene_add_image", "hpt_scene_add_material",
     "hpt_scene_add_node", "hpt_scene_set_background", "hpt_scene_set_environment", "hpt_scene_set_camera", "hpt_scene_commit",
     "hpt_trace_rays", "hpt_trace_rays_device", "hpt_scene_intersect", "hpt_render", "hpt_render_device", "hpt_render_samples",
+    "hpt_scene_info", "hpt_render_round_device", "hpt_adaptive_select_device",
 ]
 
 
@@ -129,6 +136,9 @@ def _load():
     lib.hpt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), F32P, U32P, C.POINTER(RenderStats)]
     lib.hpt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
     lib.hpt_render_samples.argtypes = [C.c_void_p, C.POINTER(RenderParams), F32P]
+    lib.hpt_scene_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+    lib.hpt_render_round_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
+    lib.hpt_adaptive_select_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, F32P, C.c_void_p, C.c_void_p, C.c_uint32, U32P]
     return lib
 
 
@@ -309,6 +319,26 @@ class Scene:
         st = RenderStats()
         check(lib.hpt_render_device(self.h, C.byref(p), C.c_void_p(out_ptr), C.byref(st) if want_stats else None))
         return st
+
+    def info(self):
+        out = SceneInfo()
+        check(lib.hpt_scene_info(self.h, C.byref(out)))
+        return out
+
+    def render_round_device(self, accum_ptr, minmax_ptr, pixel_list_ptr, n_pixels, want_stats=False, **kw):
+        """one adaptive round on device buffers (hpt_render_round_device); pixel_list_ptr = 0 for every pixel"""
+        p = self.params(**kw)
+        st = RenderStats()
+        check(lib.hpt_render_round_device(self.h, C.byref(p), C.c_void_p(pixel_list_ptr or None), n_pixels, C.c_void_p(accum_ptr),
+                                          C.c_void_p(minmax_ptr or None), C.byref(st) if want_stats else None))
+        return st
+
+    def adaptive_select_device(self, list_in_ptr, n_in, minmax_ptr, thresholds, list_out_ptr, spp_ptr, next_num_samples):
+        thr = (C.c_float * 3)(*[float(t) for t in thresholds])
+        n_out = C.c_uint32(0)
+        check(lib.hpt_adaptive_select_device(self.h, C.c_void_p(list_in_ptr or None), n_in, C.c_void_p(minmax_ptr), thr, C.c_void_p(list_out_ptr),
+                                             C.c_void_p(spp_ptr), next_num_samples, C.byref(n_out)))
+        return n_out.value
 
     def render_samples(self, **kw):
         p = self.params(**kw)

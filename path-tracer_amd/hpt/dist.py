@@ -19,3 +19,76 @@ def reduce_sum(tensor, dst=0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
     return tensor
+
+
+def allreduce_minmax(minmax):
+    """Per-channel running min/max planes (npix x 6: min rgb, max rgb) combined over ranks with ONE collective:
+    max over [-min, max] (exact: negation is exact, +inf -> -inf)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return minmax
+    v = minmax.view(-1, 6)
+    v[:, :3].neg_()
+    dist.all_reduce(minmax, op=dist.ReduceOp.MAX)
+    v[:, :3].neg_()
+    return minmax
+
+
+class DeviceRounds:
+    """The adaptive rounds of one rank on its GPU (hpt_render_round_device / hpt_adaptive_select_device) behind the small
+    interface render_adaptive() drives: new_buffers, render_round, select.  Work is enqueued on torch's current stream
+    (the context is pointed at it) so that the collectives between rounds are ordered after the kernels."""
+
+    def __init__(self, scene, max_depth=8, seed=1, spp_per_pass=0):
+        import torch
+        self.torch = torch
+        self.scene, self.max_depth, self.seed, self.spp_per_pass = scene, max_depth, seed, spp_per_pass
+        self.npix = scene.width * scene.height
+        scene.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.lists = [torch.empty(self.npix, dtype=torch.int32, device="cuda") for _ in range(2)]
+        self.cur = -1
+        self.rays = 0
+
+    def new_buffers(self, initial_samples):
+        t = self.torch
+        accum = t.zeros(self.npix * 3, dtype=t.float32, device="cuda")
+        minmax = t.empty((self.npix, 6), dtype=t.float32, device="cuda")
+        minmax[:, :3] = float("inf"); minmax[:, 3:] = 0.0          # main.rs:90-92
+        spp = t.full((self.npix,), int(initial_samples), dtype=t.int32, device="cuda")
+        return accum, minmax, spp
+
+    def render_round(self, first_sample, count, n_active, accum, minmax):
+        plist = 0 if self.cur < 0 else self.lists[self.cur].data_ptr()
+        st = self.scene.render_round_device(accum.data_ptr(), minmax.data_ptr(), plist, n_active, want_stats=True, spp=count,
+                                            first_sample=first_sample, max_depth=self.max_depth, seed=self.seed, spp_per_pass=self.spp_per_pass)
+        self.rays += st.rays_primary + st.rays_bounce
+
+    def select(self, n_active, minmax, thresholds, spp, next_num_samples):
+        nxt = 0 if self.cur < 0 else 1 - self.cur
+        n = self.scene.adaptive_select_device(0 if self.cur < 0 else self.lists[self.cur].data_ptr(), n_active, minmax.data_ptr(), thresholds,
+                                              self.lists[nxt].data_ptr(), spp.data_ptr(), next_num_samples)
+        self.cur = nxt
+        return n
+
+
+def render_adaptive(engine, rank=0, world=1, initial_samples=128, max_samples=512, thresholds=(0.4, 0.3, 0.6)):
+    """main.rs:67-110 over `world` ranks: in every round (samples have+1..num of the still-active pixels) rank
+    r renders its contiguous share of the round's samples; the min/max planes are all-reduced so that every rank runs
+    the contrast test on identical data and keeps an identical active set; the float sums are reduced once at the end.
+    Returns (rgb [npix,3] on rank 0 else None, samples_per_px)."""
+    accum, minmax, spp = engine.new_buffers(initial_samples)
+    have, num, n_active = 0, int(initial_samples), engine.npix
+    while n_active > 0:
+        lo, cnt = sample_range(rank, world, num - have)
+        if cnt > 0:
+            engine.render_round(have + lo, cnt, n_active, accum, minmax)
+        allreduce_minmax(minmax)
+        have = num
+        if num >= max_samples:          # main.rs:101, first clause
+            break
+        n_active = engine.select(n_active, minmax, thresholds, spp, num * 2)
+        num *= 2
+    reduce_sum(accum, dst=0)
+    if rank != 0:
+        return None, spp
+    return accum.view(-1, 3) / spp.view(-1, 1).to(accum.dtype), spp

@@ -6,7 +6,7 @@ import numpy as np, torch
 import hpt
 from hpt import scene_io, host_bvh
 
-def run(name, desc, tree=True, spp=16, S=4, depth=8, variant=None, bpc=None):
+def run(name, desc, tree=True, spp=16, S=4, depth=8, bpc=None):
     ctx = run.ctx
     if bpc is not None: hpt.lib.hpt_debug_set_extend_blocks(ctx.h, bpc)
     sc = hpt.Scene(ctx, desc, host_bvh=(lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if tree else None)
@@ -35,26 +35,12 @@ def main():
         elif w == "nosphere":
             d.nodes = [n for n in d.nodes if n.geom != 1]
             run("no sphere", d)
-        elif w.startswith("V"):
-            for rep in range(2):
-                for v in [int(c) for c in w[1:].split(",")]:
-                    run("variant %d (rep %d)" % (v, rep), d, variant=v)
-        elif w.startswith("NT"):
-            d.nodes = [n for n in d.nodes if n.geom != 3]; d.meshes = []
-            for v in [int(c) for c in w[2:].split(",")]:
-                run("no teapot, variant %d" % v, d, variant=v)
         elif w.startswith("R"):
             for rep in range(2):
                 for r in [int(c) for c in w[1:].split(",")]:
                     hpt.lib.hpt_debug_set_refill(r)
                     run("refill %d (rep %d)" % (r, rep), d)
             hpt.lib.hpt_debug_set_refill(16)
-        elif w.startswith("P"):
-            for rep in range(2):
-                for r in [int(c) for c in w[1:].split(",")]:
-                    hpt.lib.hpt_debug_set_park(r)
-                    run("park %d (rep %d)" % (r, rep), d)
-            hpt.lib.hpt_debug_set_park(24)
         elif w.startswith("B"):
             for b in [int(c) for c in w[1:].split(",")]:
                 run("blocks/CU %d" % b, d, bpc=b)

@@ -155,3 +155,51 @@ def test_render_device_matches_host_entry(ctx, desc):
     np.testing.assert_array_equal((out.cpu().numpy().reshape(48, 64, 3) / np.float32(8)), img)
     assert st.seconds_extend > 0 and st.launches_extend == 9 and st.nodes_visited > 0 and st.inst_tests == 9 * (st.rays_primary + st.rays_bounce)
     gsc.close()
+
+
+def test_adaptive_rounds_api(ctx, olib, desc):
+    """hpt_render_round_device / hpt_adaptive_select_device (the per-rank pieces of a multi-GPU adaptive render):
+    driven by hpt.dist.render_adaptive on one rank they reproduce hpt_render's adaptive mode exactly; a round split
+    into two sample sub-ranges gives the same sums and min/max; scene info is reported."""
+    import torch
+    import hpt
+    from hpt.dist import DeviceRounds, render_adaptive
+    d = resized(desc, 64, 48)
+    sc = hpt.Scene(ctx, d, host_bvh=host_tree)
+    info = sc.info()
+    assert info.n_instances == 9 and info.n_mesh_instances == 1 and info.n_triangles == 6320 and info.uses_tlas == 0
+    assert info.n_nodes == 6319 and info.device_bytes > 6319 * 64 + 6320 * 48
+    ref = sc.render(adaptive=True, initial=8, max_samples=32, max_depth=4, seed=3)
+    eng = DeviceRounds(sc, max_depth=4, seed=3)
+    rgb, spp = render_adaptive(eng, 0, 1, initial_samples=8, max_samples=32)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(spp.cpu().numpy().reshape(48, 64), ref["samples"])
+    assert len(np.unique(ref["samples"])) >= 2
+    np.testing.assert_array_equal(rgb.cpu().numpy().reshape(48, 64, 3), ref["rgb"])
+    assert eng.rays == ref["stats"].rays_primary + ref["stats"].rays_bounce
+    # one round of 8 samples == samples 0..3 then 4..7 into the same buffers, on a pixel subset
+    npix = 64 * 48
+    plist = torch.arange(5, npix, 7, dtype=torch.int32, device="cuda")
+    bufs = []
+    for split in ((8,), (4, 4), (3, 5)):
+        acc, mm, _ = eng.new_buffers(8)
+        first = 0
+        for cnt in split:
+            sc.render_round_device(acc.data_ptr(), mm.data_ptr(), plist.data_ptr(), len(plist), spp=cnt, first_sample=first, max_depth=4, seed=3)
+            first += cnt
+        torch.cuda.synchronize()
+        bufs.append((acc.cpu().numpy(), mm.cpu().numpy()))
+    for acc, mm in bufs[1:]:
+        np.testing.assert_array_equal(acc, bufs[0][0]); np.testing.assert_array_equal(mm, bufs[0][1])
+    touched = np.zeros(npix, bool); touched[plist.cpu().numpy()] = True
+    assert (bufs[0][0].reshape(-1, 3)[~touched] == 0).all() and np.isinf(bufs[0][1][~touched, 0]).all()
+    # against the oracle's samples: per-pixel sums of samples 1..8
+    per = ol.OracleScene(olib, d).render(spp=8, max_depth=4, seed=3, want_samples=True)["per_sample"]
+    want = per[touched].astype(np.float64).sum(axis=1)
+    np.testing.assert_allclose(bufs[0][0].reshape(-1, 3)[touched], want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bufs[0][1][touched, :3], per[touched].min(axis=1), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(bufs[0][1][touched, 3:], per[touched].max(axis=1), rtol=1e-6, atol=1e-7)
+    acc, mm, _ = eng.new_buffers(8)
+    with pytest.raises(hpt.HptError):
+        sc.render_round_device(acc.data_ptr(), mm.data_ptr(), 0, 0, spp=4, adaptive=True)
+    sc.close()
