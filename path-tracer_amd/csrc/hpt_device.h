@@ -21,7 +21,14 @@
 #define HPT_MAX_DEPTH_LIMIT 64   // max bounces (size of the per-depth live-count array)
 #define HPT_NODE_CACHE 0         // interior nodes staged in LDS per workgroup (breadth-first prefix of the node array)
 #define HPT_SHARDS 64            // segments per wavefront queue (one append counter each)
-#define HPT_QUEUE_CAP 1024       // LDS work queue of k_extend: rays that entered a mesh box, waiting for traversal
+#ifndef HPT_COUNT_STRIDE
+#define HPT_COUNT_STRIDE 32      // uint32 slots between two append counters: one counter per 128-B line (L2 atomics to one line serialise)
+#endif
+#define HPT_COUNTS_PER_DEPTH (HPT_SHARDS * HPT_COUNT_STRIDE)
+#ifndef HPT_QUEUE_CAP
+#define HPT_QUEUE_CAP 1024
+#endif
+//      HPT_QUEUE_CAP         // LDS work queue of k_extend: rays that entered a mesh box, waiting for traversal
 
 struct DMesh {
     int32_t root_ref;     // ref of the root (interior index or ~tri for a one-triangle mesh)
@@ -100,7 +107,7 @@ struct DPass {
     float4* hit;         // (t, u, v, as_float(global tri or -1))
     uint32_t* hit_inst;  // instance | side<<31, HPT_MISS_INST on miss
     float4* radiance;    // per path id: (L.rgb, 0)
-    uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2][HPT_SHARDS] live paths per depth and queue segment
+    uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2][HPT_SHARDS] live paths per depth and queue segment, HPT_COUNT_STRIDE apart
     uint32_t shard_cap;  // slots per segment (multiple of HPT_BLOCK); a queue holds HPT_SHARDS * shard_cap slots
     const float2* halton;        // [S] (halton(i,2), halton(i,3)) of this pass's samples
     const uint32_t* pixel_list;  // adaptive: active pixels of this pass (NULL = all pixels, slot == pixel)

@@ -18,6 +18,15 @@
 #include "hpt_launch.h"
 
 #define PI_F 3.14159265358979323846f
+// register budgets (waves per SIMD the allocator must reach) of the two hot kernels; see DESIGN.md tuning log
+#ifndef HPT_EXTEND_WAVES
+#define HPT_EXTEND_WAVES 4
+#endif
+#ifndef HPT_SHADE_WAVES
+#define HPT_SHADE_WAVES 4
+#endif
+#define HPT_EXTEND_OCC __attribute__((amdgpu_waves_per_eu(HPT_EXTEND_WAVES, HPT_EXTEND_WAVES)))
+#define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
 
 // ------------------------------------------------------------------------------------------------ vector helpers
@@ -271,7 +280,7 @@ struct WorkView { const uint32_t* counts; uint32_t cap; uint32_t shards; uint32_
 __device__ __forceinline__ uint32_t work_items(const WorkView& wv) { return wv.shards * (wv.cap / HPT_BLOCK); }
 __device__ __forceinline__ bool work_slot(const WorkView& wv, uint32_t w, uint32_t& slot) {
     const uint32_t s = w % wv.shards, k = w / wv.shards;
-    const uint32_t cnt = wv.counts ? wv.counts[s] : wv.n_linear;
+    const uint32_t cnt = wv.counts ? wv.counts[s * HPT_COUNT_STRIDE] : wv.n_linear;
     const uint32_t off = k * HPT_BLOCK + threadIdx.x;
     slot = s * wv.cap + off;
     return off < cnt;
@@ -594,7 +603,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
     const uint32_t groups_per_seg = (wv.cap + GROUP - 1) / GROUP, total = wv.shards * groups_per_seg;
     for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
         const uint32_t s = w % wv.shards, g = w / wv.shards;
-        const uint32_t cnt = wv.counts ? wv.counts[s] : wv.n_linear;
+        const uint32_t cnt = wv.counts ? wv.counts[s * HPT_COUNT_STRIDE] : wv.n_linear;
         const uint32_t first = g * GROUP;
         if (threadIdx.x == 0) *L.qhead = 0;
         __syncthreads();
@@ -679,19 +688,19 @@ k_raygen(DScene sc, DPass ps) {
             cnt = mine * HPT_BLOCK;
             if ((chunks - 1) % HPT_SHARDS == seg) cnt -= chunks * HPT_BLOCK - n;   // the last chunk is mine and partial
         }
-        ps.counts[seg] = cnt;
+        ps.counts[seg * HPT_COUNT_STRIDE] = cnt;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ k_extend
 template <bool COUNT>
-__global__ void __launch_bounds__(HPT_BLOCK)
+__global__ void __launch_bounds__(HPT_BLOCK) HPT_EXTEND_OCC
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     Lds L = lds_carve(stack_entries);
     L.refill = refill;
     lds_load_nodes(L, sc.nodes, sc.n_nodes);
     const DQueue& q = ps.q[depth & 1];
-    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_SHARDS; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
+    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
     if (sc.use_tlas) block_closest_hit_tlas<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     else block_closest_hit<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
@@ -872,7 +881,7 @@ k_scene_hitinfo(DScene sc, long long n, const float4* __restrict__ org, const fl
 // One bounce of Scene::cast (scene.rs:130-188) in forward (throughput) form + append of the surviving paths to the
 // next queue.  radiance[path] += throughput * emission replaces the recursion's `color = emission + f * next`.
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(HPT_BLOCK)
+__global__ void __launch_bounds__(HPT_BLOCK) HPT_SHADE_OCC
 k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
     Tables T;
     if constexpr (LDS_SCENE) {
@@ -894,8 +903,8 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
     }
     const DQueue& qi = ps.q[depth & 1];
     const DQueue& qo = ps.q[(depth + 1) & 1];
-    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_SHARDS; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
-    uint32_t* counts_out = ps.counts + (size_t)(depth + 1) * HPT_SHARDS;
+    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
+    uint32_t* counts_out = ps.counts + (size_t)(depth + 1) * HPT_COUNTS_PER_DEPTH;
     const int lane = threadIdx.x & 63;
     const uint32_t total = work_items(wv);
     for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
@@ -996,7 +1005,7 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&counts_out[seg], (uint32_t)__popcll(mask));   // survivors stay in their segment
+            if (lane == 0) wbase = atomicAdd(&counts_out[seg * HPT_COUNT_STRIDE], (uint32_t)__popcll(mask));   // survivors stay in their segment
             wbase = __shfl(wbase, 0);
             if (alive) {
                 const uint32_t dst = seg * ps.shard_cap + wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -1040,7 +1049,7 @@ __global__ void k_finish_pass(DPass ps) {
         unsigned long long tot = 0;
         unsigned long long prim = 0;
         for (int d = 0; d <= ps.max_depth; ++d)
-            for (int s = 0; s < HPT_SHARDS; ++s) { tot += ps.counts[d * HPT_SHARDS + s]; if (d == 0) prim += ps.counts[s]; }
+            for (int s = 0; s < HPT_SHARDS; ++s) { tot += ps.counts[d * HPT_COUNTS_PER_DEPTH + s * HPT_COUNT_STRIDE]; if (d == 0) prim += ps.counts[s * HPT_COUNT_STRIDE]; }
         ps.stat[0] += tot;
         ps.stat[4] += prim;
     }

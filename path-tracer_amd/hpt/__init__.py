@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libhpt.so")
+LIB_PATH = os.environ.get("HPT_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libhpt.so")   # HPT_LIB_PATH: A/B builds in tuning runs
 
 F32P = C.POINTER(C.c_float)
 U32P = C.POINTER(C.c_uint32)
