@@ -20,7 +20,10 @@
 #define HPT_MISS_INST 0x7fffffffu
 #define HPT_MAX_DEPTH_LIMIT 64   // max bounces (size of the per-depth live-count array)
 #define HPT_NODE_CACHE 0         // interior nodes staged in LDS per workgroup (breadth-first prefix of the node array)
-#define HPT_SHARDS 64            // segments per wavefront queue (one append counter each)
+#ifndef HPT_SHARDS
+#define HPT_SHARDS 64
+#endif
+//      HPT_SHARDS               // segments per wavefront queue (one append counter each)
 #ifndef HPT_COUNT_STRIDE
 #define HPT_COUNT_STRIDE 32      // uint32 slots between two append counters: one counter per 128-B line (L2 atomics to one line serialise)
 #endif

@@ -805,7 +805,9 @@ struct WorldHit { f3 pos, normal, uv; int side; int material; int node_id; int p
 struct Tables { const DInstance* inst; const DXformInv* xinv; const DXformFwd* xfwd; const DMaterial* mats; };
 __device__ __forceinline__ Tables global_tables(const DScene& sc) { Tables T; T.inst = sc.instances; T.xinv = sc.xinv; T.xfwd = sc.xfwd; T.mats = sc.materials; return T; }
 
-__device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T, f3 o, f3 d, float t, float bu, float bv, int prim, uint32_t inst_side) {
+// need_uv = false skips the sphere's lat-long uv (atan2f + asinf, geometry.rs:61-64) when no texture of the hit
+// material reads it (all Blank: scene.rs:313 ignores the point) -- the result of the shade is unchanged.
+__device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T, f3 o, f3 d, float t, float bu, float bv, int prim, uint32_t inst_side, bool need_uv) {
     WorldHit w;
     const DInstance& in = T.inst[inst_side & 0x7fffffffu];
     w.side = (int)(inst_side >> 31);
@@ -822,7 +824,8 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
     }
     if (in.geom == 1) {
         normal = normalize3(pos);
-        uv = mk3(0.5f + atan2f(normal.y, normal.x) / (2.0f * PI_F), 0.5f - asinf(-normal.z) / PI_F, 0.0f);
+        uv = mk3(0, 0, 0);
+        if (need_uv) uv = mk3(0.5f + atan2f(normal.y, normal.x) / (2.0f * PI_F), 0.5f - asinf(-normal.z) / PI_F, 0.0f);
     } else if (in.geom == 2) {
         uv = mk3(0.5f + 0.5f * pos.x, 0.5f + 0.5f * pos.y, 0.0f);
         normal = mk3(0, 0, 1);
@@ -831,7 +834,8 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
         const float wgt = 1.0f - bu - bv;
         pos = add3(add3(scale3(ld3(s + 0), wgt), scale3(ld3(s + 3), bu)), scale3(ld3(s + 6), bv));
         normal = add3(add3(scale3(ld3(s + 9), wgt), scale3(ld3(s + 12), bu)), scale3(ld3(s + 15), bv));
-        uv = add3(add3(scale3(ld3(s + 18), wgt), scale3(ld3(s + 21), bu)), scale3(ld3(s + 24), bv));
+        uv = mk3(0, 0, 0);
+        if (need_uv) uv = add3(add3(scale3(ld3(s + 18), wgt), scale3(ld3(s + 21), bu)), scale3(ld3(s + 24), bv));
         w.prim_local = prim - sc.meshes[in.mesh].tri_base;   // only read by the test entry (dead code in k_shade)
     }
     for (int k = in.xf_count - 1; k >= 0; --k) {
@@ -868,7 +872,7 @@ k_scene_hitinfo(DScene sc, long long n, const float4* __restrict__ org, const fl
             node[i] = -1; prim[i] = -1; t[i] = 0.0f; side[i] = 0;
             pos[i] = make_float4(0, 0, 0, 0); normal[i] = make_float4(0, 0, 0, 0); uvw[i] = make_float4(0, 0, 0, 0);
         } else {
-            const WorldHit w = world_hit(sc, global_tables(sc), xyz(org[i]), xyz(dir[i]), h.x, h.y, h.z, __float_as_int(h.w), is);
+            const WorldHit w = world_hit(sc, global_tables(sc), xyz(org[i]), xyz(dir[i]), h.x, h.y, h.z, __float_as_int(h.w), is, true);
             node[i] = w.node_id; prim[i] = w.prim_local; t[i] = h.x; side[i] = (uint8_t)w.side;
             pos[i] = make_float4(w.pos.x, w.pos.y, w.pos.z, 0);
             normal[i] = make_float4(w.normal.x, w.normal.y, w.normal.z, 0);
@@ -939,8 +943,9 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                     }
                 }
             } else {
-                const WorldHit w = world_hit(sc, T, o, d, h4.x, h4.y, h4.z, __float_as_int(h4.w), inst_side);
-                const DMaterial& mat = T.mats[w.material];
+                const DMaterial& mat = T.mats[T.inst[inst_side & 0x7fffffffu].material];
+                const bool need_uv = (mat.diffuse.kind | mat.reflection.kind | mat.refraction.kind) != 0;
+                const WorldHit w = world_hit(sc, T, o, d, h4.x, h4.y, h4.z, __float_as_int(h4.w), inst_side, need_uv);
                 const f3 diffuse = texture_sample(sc, mat.diffuse, w.uv);
                 const f3 reflection = texture_sample(sc, mat.reflection, w.uv);
                 const f3 refraction = texture_sample(sc, mat.refraction, w.uv);
