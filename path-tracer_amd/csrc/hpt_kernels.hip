@@ -23,7 +23,7 @@
 #define HPT_EXTEND_WAVES 4
 #endif
 #ifndef HPT_SHADE_WAVES
-#define HPT_SHADE_WAVES 4
+#define HPT_SHADE_WAVES 5
 #endif
 #define HPT_EXTEND_OCC __attribute__((amdgpu_waves_per_eu(HPT_EXTEND_WAVES, HPT_EXTEND_WAVES)))
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
@@ -69,6 +69,22 @@ __device__ __forceinline__ RngKey rng_key(uint32_t seed, uint32_t pixel, uint32_
 __device__ __forceinline__ float rng_f32(RngKey k, uint32_t dim) {
     uint32_t h = mix32(k.k1 ^ mix32(k.k2 + dim * 0x9E3779B9U));
     return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ uniform table reads
+// Scene tables read at a wave-uniform index (the instance loop of phase 1) go through the constant address space:
+// the backend then emits scalar loads (s_load_dwordx8/x16 into SGPRs, one wait per record).  Through a plain global
+// pointer it emitted one VECTOR load per field, each followed by s_waitcnt vmcnt(0): five dependent round trips per
+// instance.  The tables are written by hipMemcpy before the launch and never by a kernel.
+#define HPT_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T* table, int index) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    const HPT_CONST_AS uint32_t* w = (const HPT_CONST_AS uint32_t*)(table + index);
+    union U { T v; uint32_t d[sizeof(T) / 4]; __device__ U() {} } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) u.d[i] = w[i];
+    return u.v;
 }
 
 // ------------------------------------------------------------------------------------------------ transforms
@@ -293,14 +309,14 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
     int mpos = -1, mcount = 0;
     f3 lo0 = o, ld0 = d;
     for (int k = 0; k < sc.n_instances; ++k) {
-        const DInstance& in = sc.instances[k];      // uniform address: scalar loads
+        const DInstance in = load_uniform(sc.instances, k);      // wave-uniform record: scalar loads
         if (!in.shared_top) { lo0 = o; ld0 = d; ray_level(in.lv[0], lo0, ld0); }
         if (in.geom == 3) {
             if (mpos < 0) {
                 f3 lo = lo0, ld = ld0;
                 ray_rest_levels(sc, in, lo, ld);
                 if (COUNT) n_inst++;
-                const DMesh& mesh = sc.meshes[in.mesh];
+                const DMesh mesh = load_uniform(sc.meshes, in.mesh);
                 const RayBox rb = make_raybox(lo, ld);
                 float tin;
                 if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin)) mpos = mcount;
@@ -397,6 +413,8 @@ __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsi
         // ---- traversal steps until enough lanes are done (all of them once the queue is empty)
         const int keep_going_above = exhausted ? 0 : 64 - L.refill;
         while (__popcll(__ballot(ref != SENTINEL)) > keep_going_above) {
+            // (gating the triangle block on ">= K lanes wait at a leaf" measured +-1 % for K = 2..8 and slower above:
+            // what it saves in instructions it loses in idle lanes)
             if (ref >= 0) {
                 const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
                 const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
