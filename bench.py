@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra library-SAH-tree measurement")
     ap.add_argument("--tree", choices=["host", "sah"], default="host", help="host: reference bvh.rs tree handed over (drop-in); sah: library-built")
     args = ap.parse_args()
 
@@ -192,6 +193,18 @@ def main():
                          "avg_launch_ms": round(ext_s_local / max(ext_launches, 1) * 1e3, 4), "launches": int(ext_launches),
                          "extend_share_of_step": round(ext_s_local / (elapsed), 3), "shade_share_of_step": round(shade_s_local / elapsed, 3)},
         }
+        if world == 1 and args.tree == "host" and not args.no_alt:
+            # the same frame with the library's own SAH tree (hpt_scene_add_mesh(nodes = NULL)): identical hits by the
+            # deterministic tie rule, fewer node visits.  Reported beside `value`, which keeps the host-built tree.
+            alt = hpt.Scene(ctx, desc, host_bvh=None)
+            with torch.cuda.stream(stream):
+                alt.render_device(accum.data_ptr(), want_stats=True, spp=min(count, 64), first_sample=first, max_depth=args.depth, seed=1)
+                stream.synchronize(); t1 = time.perf_counter()
+                ast = alt.render_device(accum.data_ptr(), want_stats=True, spp=count, first_sample=first, max_depth=args.depth, seed=1,
+                                        spp_per_pass=args.spp_per_pass)
+                stream.synchronize(); dt = time.perf_counter() - t1
+            line["library_sah_tree"] = {"value": round((ast.rays_primary + ast.rays_bounce) / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt * 1e3, 3)}
+            alt.close()
         if world == 1 and args.cpu_spp > 0:
             cb, cpu_img = cpu_baseline(desc, args.cpu_spp, args.depth, 1)
             line["cpu_baseline"] = cb

@@ -1,0 +1,91 @@
+// hpt_render -- the reference's command line on top of libhpt.so:
+//     cargo run --release -- scene.xml out.png      ==>      hpt_render scene.xml out.png
+// main.rs:34-41 (arguments), load_scene (load.rs:17), the pixel loop of main.rs:55-115 replaced by ONE hpt_render call
+// (adaptive sampling with the constants of main.rs:27-32 unless --spp is given), color_as_u8_array (scene.rs:362) via
+// hpt_tonemap_rgba8, save_img (main.rs:117-130).  Errors end the process with exit code 101 like a Rust panic.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+#include "hpt_host.h"
+
+using namespace hpt_host;
+
+static void usage() {
+    std::fprintf(stderr,
+        "usage: hpt_render <scene.xml> <out.png> [options]\n"
+        "  --spp N            fixed N samples per pixel (default: the reference's adaptive 128 -> 512 sampling)\n"
+        "  --depth D          bounce cap (default 8; the reference recursion is unbounded, see DESIGN.md)\n"
+        "  --seed S           seed of the counter-based generator (default 1)\n"
+        "  --size WxH         override <width>/<height> of the scene file\n"
+        "  --device I         GPU index (default 0)\n"
+        "  --library-bvh      let the library build its SAH tree instead of handing over the bvh.rs tree\n"
+        "  --stats            print ray counts and timings to stderr\n"
+        "  --dump-scene FILE  write the loaded scene (exact float bits + digests) and exit; needs no GPU\n");
+}
+
+int main(int argc, char** argv) {
+    try {
+        std::vector<std::string> pos;
+        int spp = 0, depth = 8, device = 0; unsigned seed = 1; bool library_bvh = false, stats = false;
+        int ow = 0, oh = 0; std::string dump;
+        for (int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto val = [&]() -> const char* { if (i + 1 >= argc) throw Error("missing value after " + a); return argv[++i]; };
+            if (a == "--spp") spp = std::atoi(val());
+            else if (a == "--depth") depth = std::atoi(val());
+            else if (a == "--seed") seed = (unsigned)std::strtoul(val(), nullptr, 10);
+            else if (a == "--device") device = std::atoi(val());
+            else if (a == "--size") { if (std::sscanf(val(), "%dx%d", &ow, &oh) != 2 || ow <= 0 || oh <= 0) throw Error("--size wants WxH"); }
+            else if (a == "--library-bvh") library_bvh = true;
+            else if (a == "--stats") stats = true;
+            else if (a == "--dump-scene") dump = val();
+            else if (a == "-h" || a == "--help") { usage(); return 0; }
+            else pos.push_back(a);
+        }
+        if (!dump.empty() && pos.size() >= 1) {
+            const SceneDesc d = load_scene(pos[0], true);
+            std::ofstream f(dump);
+            if (!f) throw Error("cannot create " + dump);
+            f << dump_scene(d);
+            return 0;
+        }
+        if (pos.size() < 2) { usage(); throw Error("please provide a scene description file and an image output file"); }   // main.rs:36-38
+
+        SceneDesc d = load_scene(pos[0], !library_bvh);
+        if (ow) { d.camera.img_width = (uint32_t)ow; d.camera.img_height = (uint32_t)oh; }
+
+        hpt_context* ctx = nullptr; hpt_scene* scene = nullptr;
+        if (hpt_context_create(device, &ctx) != HPT_OK) throw Error(std::string("hpt_context_create: ") + hpt_last_error());
+        if (hpt_scene_create(ctx, &scene) != HPT_OK) throw Error(std::string("hpt_scene_create: ") + hpt_last_error());
+        hand_over(d, scene, library_bvh);
+
+        hpt_render_params p; std::memset(&p, 0, sizeof p);
+        p.adaptive = spp > 0 ? 0 : 1; p.spp = spp;
+        p.initial_samples = 128; p.max_samples = 512;                       // main.rs:31-32
+        p.thresholds[0] = 0.4f; p.thresholds[1] = 0.3f; p.thresholds[2] = 0.6f;   // main.rs:27-29
+        p.max_depth = depth; p.seed = seed;
+        if (stats) p.flags = HPT_RENDER_TIME_KERNELS;
+        const size_t npix = (size_t)d.camera.img_width * d.camera.img_height;
+        std::vector<float> rgb(npix * 3);
+        std::vector<uint32_t> counts(npix);
+        hpt_render_stats st;
+        if (hpt_render(scene, &p, rgb.data(), counts.data(), &st) != HPT_OK) throw Error(std::string("hpt_render: ") + hpt_last_error());
+        std::vector<uint8_t> rgba(npix * 4);
+        if (hpt_tonemap_rgba8(rgb.data(), (uint32_t)npix, rgba.data()) != HPT_OK) throw Error(std::string("hpt_tonemap_rgba8: ") + hpt_last_error());
+        write_png_rgba8(pos[1], d.camera.img_width, d.camera.img_height, rgba.data());   // main.rs:117
+        if (stats) {
+            const double rays = (double)(st.rays_primary + st.rays_bounce);
+            std::fprintf(stderr, "%ux%u, %llu pixel-samples, %.0f rays in %.3f s = %.1f Mrays/s (extend %.3f s, shade %.3f s, %u passes)\n",
+                         d.camera.img_width, d.camera.img_height, (unsigned long long)st.samples, rays, st.seconds_total, rays / st.seconds_total / 1e6,
+                         st.seconds_extend, st.seconds_shade, st.passes);
+        }
+        hpt_scene_destroy(scene); hpt_context_destroy(ctx);
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "hpt_render: %s\n", e.what());
+        return 101;   // Rust's panic exit code: the reference panics on every load / IO error
+    }
+}

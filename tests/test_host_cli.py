@@ -1,0 +1,166 @@
+"""The C++ host side (path-tracer_amd/host: load.rs / bvh.rs build / main.rs mirrored above the C ABI) against its
+Python twin (hpt/scene_io.py, hpt/host_bvh.py): same scene bits, same BVH node array, same PNG bytes.  The loader
+checks need no GPU (`hpt_render --dump-scene`); the render check goes through libhpt.so on the GPU."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, host_tree
+
+CLI = os.path.join(ROOT, "path-tracer_amd", "hpt_render")
+
+
+def fnv1a(arr):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(arr).tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def fnv1a_fast(arr):
+    """same digest, vectorised enough for the 12 639-node arrays: plain loop over bytes in chunks"""
+    data = np.ascontiguousarray(arr).tobytes()
+    h = 1469598103934665603
+    mask = 0xFFFFFFFFFFFFFFFF
+    for b in data:
+        h = ((h ^ b) * 1099511628211) & mask
+    return h
+
+
+def bits(v):
+    return "".join(" %08x" % int(x) for x in np.atleast_1d(np.asarray(v, dtype=np.float32)).view(np.uint32))
+
+
+def py_dump(desc, trees):
+    out = []
+
+    def tex(name, t):
+        out.append("%s %d %d%s%s%s%s%s" % (name, t.kind, t.image, bits(t.color), bits(t.color1), bits(t.color2), bits(t.m), bits(t.t)))
+    c = desc.camera
+    out.append("camera %d %d%s%s%s%s%s%s" % (c.width, c.height, bits(c.pos), bits(c.dir), bits(c.up), bits(c.fov), bits(c.focaldist), bits(c.dof)))
+    tex("background", desc.background); tex("environment", desc.environment)
+    for i, m in enumerate(desc.materials):
+        out.append("material %d %s%s%s%s%s" % (i, m.name, bits(m.emission), bits(m.reflection_glossiness), bits(m.refraction_glossiness), bits(m.refraction_index)))
+        tex(" diffuse", m.diffuse); tex(" reflection", m.reflection); tex(" refraction", m.refraction)
+    for i, n in enumerate(desc.nodes):
+        out.append("node %d %d %d %d %d%s%s" % (i, n.parent, n.geom, n.mesh, n.material, bits(n.m), bits(n.t)))
+    for i, m in enumerate(desc.meshes):
+        t = trees[i]
+        out.append("mesh %d nv %d nn %d nt %d ntri %d verts %016x normals %016x uvw %016x tris %016x ntris %016x ttris %016x bvh %d %016x" % (
+            i, len(m.verts), len(m.normals), len(m.uvw), len(m.tris), fnv1a_fast(m.verts), fnv1a_fast(m.normals), fnv1a_fast(m.uvw),
+            fnv1a_fast(m.tris.astype(np.uint32)), fnv1a_fast(m.ntris.astype(np.uint32)), fnv1a_fast(m.ttris.astype(np.uint32)), len(t), fnv1a_fast(t)))
+    for i, im in enumerate(desc.images):
+        out.append("image %d %d %d %016x" % (i, im.shape[1], im.shape[0], fnv1a_fast(im)))
+    return "\n".join(out) + "\n"
+
+
+def cli_dump(scene_path, tmp_path):
+    out = str(tmp_path / "dump.txt")
+    r = subprocess.run([CLI, "--dump-scene", out, scene_path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return open(out).read()
+
+
+def test_cli_built():
+    assert os.path.exists(CLI), "run `make -C path-tracer_amd` (or __graft_entry__.build())"
+
+
+def test_golden_scene_same_bits(desc, tmp_path):
+    """scene.xml + teapot.obj: every float the two loaders produce is bit-identical, and so is the bvh.rs tree
+    (12 639 nodes) the C++ host builds"""
+    got = cli_dump(os.path.join(GOLDEN, "scene.xml"), tmp_path)
+    want = py_dump(desc, [host_tree(m) for m in desc.meshes])
+    assert got.splitlines() == want.splitlines()
+
+
+def write_png(path, img, level=6):
+    h, w, ch = img.shape
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b""))
+
+
+SCENE = """<xml>
+  <scene>
+    <!-- a comment -->
+    <background r="0.2" g="0.3" b="0.4" texture="checkerboard"><color1 r="1" g="0" b="0"/><color2 r="0" g="1" b="0"/><scale x="0.25" y="0.5"/></background>
+    <environment value="0.8" texture="env.png"><rotate angle="33" y="1"/><translate x="0.1"/></environment>
+    <object name="grp"><scale value="2"/><rotate angle="20" x="1"/><translate x="1" y="2" z="3"/>
+      <object type="sphere" name="s" material="glass"><scale x="1" y="2" z="0.5"/><rotate angle="-75.5" z="1"/></object>
+      <object type="plane" name="p" material='img'><translate z="-1"/>
+        <object type="sphere" material="glass"><translate z="1"/></object>
+      </object>
+    </object>
+    <material type="blinn" name="glass"><diffuse value="0"/><specular value="0.8"/><reflection value="0.7" glossiness="0.05"/>
+      <refraction r="0.9" g="0.8" b="1.0" index="1.33" glossiness="0.01"/></material>
+    <material type="blinn" name="img"><diffuse texture="tex.png"><scale value="0.1"/></diffuse><specular/><emission value="2" r="1" g="0.5" b="0.25"/></material>
+    <light type="ambient"><intensity value="0.1"/></light>
+  </scene>
+  <camera><position x="0" y="-20" z="5"/><target x="0.5" y="0" z="1"/><up x="0" y="0.2" z="1"/><fov value="37.5"/>
+    <width value="40"/><height value="30"/><focaldist value="18"/><dof value="0.05"/></camera>
+</xml>
+"""
+
+
+def test_synthetic_scene_same_bits(tmp_path):
+    """nested nodes, all three transform kinds, checkerboard + PNG image textures (zlib level 9 -> dynamic Huffman blocks
+    through the C++ inflate; grey+alpha and RGB colour types), DOF camera"""
+    from hpt import scene_io
+    rng = np.random.default_rng(3)
+    write_png(str(tmp_path / "tex.png"), rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8), 9)
+    smooth = (np.add.outer(np.arange(64), np.arange(48)) % 256).astype(np.uint8)
+    write_png(str(tmp_path / "env.png"), np.stack([smooth, 255 - smooth], axis=2), 9)
+    (tmp_path / "s.xml").write_text(SCENE)
+    d = scene_io.load_scene(str(tmp_path / "s.xml"))
+    got = cli_dump(str(tmp_path / "s.xml"), tmp_path).splitlines()
+    want = py_dump(d, []).splitlines()
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        if g != w:   # rotations: libm sinf/cosf vs numpy's f32 sin/cos may differ in the last bit
+            gt, wt = g.split(), w.split()
+            assert len(gt) == len(wt)
+            for a, b in zip(gt, wt):
+                if a != b:
+                    assert len(a) == 8 and abs(int(a, 16) - int(b, 16)) <= 2, (g, w)
+
+
+def test_cli_errors(tmp_path):
+    """the reference panics (exit 101) on every load error; so does the CLI"""
+    p = tmp_path / "bad.xml"
+    for text, msg in [("<xml><camera/></xml>", "no <scene> tag found"),
+                      ('<xml><scene><object type="cube" material="m"/></scene><camera/></xml>', "unknown object type"),
+                      ('<xml><scene><material type="blinn" name="m"/></scene></xml>', "no specular"),
+                      ("<xml><scene>", "xml:")]:
+        p.write_text(text)
+        r = subprocess.run([CLI, "--dump-scene", str(tmp_path / "o.txt"), str(p)], capture_output=True, text=True)
+        assert r.returncode == 101 and msg in r.stderr, r.stderr
+    r = subprocess.run([CLI, str(p)], capture_output=True, text=True)
+    assert r.returncode == 101 and "please provide a scene description file and an image output file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_renders_same_png(ctx, desc, tmp_path):
+    """hpt_render scene.xml out.png == the Python host driving the same library: identical PNG pixels, fixed and adaptive"""
+    import hpt
+    from hpt import scene_io
+    from conftest import resized
+    d = resized(desc, 64, 48)
+    sc = hpt.Scene(ctx, d, host_bvh=host_tree)
+    for args, kw in [(["--spp", "8", "--depth", "4", "--seed", "5"], dict(spp=8, max_depth=4, seed=5)),
+                     ([], dict(adaptive=True, max_depth=8, seed=1))]:
+        out = str(tmp_path / "o.png")
+        r = subprocess.run([CLI, os.path.join(GOLDEN, "scene.xml"), out, "--size", "64x48", "--stats"] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Mrays/s" in r.stderr
+        img = scene_io.read_png_rgb8(out)
+        want = hpt.tonemap_rgba8(sc.render(**kw)["rgb"])
+        np.testing.assert_array_equal(img, want[:, :, :3])
+    sc.close()
