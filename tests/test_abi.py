@@ -68,3 +68,39 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in src and "oracle_lib" not in src and "oracle/" not in src.replace("the CPU oracle", ""), f
+
+
+def test_rust_ffi_crate_declares_every_export():
+    """rust/hpt-sys/src/lib.rs (source only: no Rust toolchain here) binds every function include/hpt.h declares, and
+    its #[repr(C)] structs have the header's field counts (sizes are checked against ctypes)"""
+    import re
+    import hpt
+    src = open(os.path.join(ROOT, "rust", "hpt-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (hpt_\w+)\(", src))
+    assert declared == set(hpt.EXPORTS)
+    hdr = open(os.path.join(ROOT, "include", "hpt.h")).read()
+    assert set(re.findall(r"\b(hpt_\w+)\(", hdr)) - {"hpt_scene_add_"} >= declared
+    # struct sizes implied by the Rust field lists (all fields 4 or 8 bytes, natural alignment) == ctypes sizes
+    sizes = {"hpt_bvh_node": hpt.BvhNode, "hpt_texture": hpt.Texture, "hpt_material": hpt.Material, "hpt_camera": hpt.Camera,
+             "hpt_render_params": hpt.RenderParams, "hpt_render_stats": hpt.RenderStats, "hpt_trace_stats": hpt.TraceStats,
+             "hpt_scene_info_t": hpt.SceneInfo}
+    prim = {"i32": 4, "u32": 4, "f32": 4, "i64": 8, "u64": 8, "f64": 8}
+    import ctypes
+    known = {}
+    for name, body in re.findall(r"pub struct (hpt_\w+)\s*\{(.*?)\n?\}", src, re.S):
+        total, align = 0, 4
+        for ftype in re.findall(r"pub \w+:\s*([^,}]+)", body):
+            ftype = ftype.strip()
+            m = re.match(r"\[(\w+); (\d+)\]", ftype)
+            if m:
+                sz, a = prim[m.group(1)] * int(m.group(2)), prim[m.group(1)]
+            elif ftype in prim:
+                sz = a = prim[ftype]
+            else:
+                sz, a = known[ftype]
+            total = (total + a - 1) // a * a + sz
+            align = max(align, a)
+        total = (total + align - 1) // align * align
+        known[name] = (total, align)
+    for name, cls in sizes.items():
+        assert known[name][0] == ctypes.sizeof(cls), name
