@@ -62,7 +62,8 @@ struct hpt_context {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int num_cus = 256;
     int max_blocks = 2048;
-    int extend_blocks = 1024;   // persistent grid of the traversal kernels (LDS-limited residency)
+    int extend_blocks = 1024;   // persistent grid of the test-entry traversal kernels
+    int extend_per_cu = 0;      // workgroups per CU of k_extend; 0 = by kernel variant and LDS need (extend_grid)
     std::vector<hipEvent_t> events;   // pool for HPT_RENDER_TIME_KERNELS
 };
 
@@ -174,7 +175,7 @@ extern "C" int hpt_context_create(int device, hpt_context** out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->max_blocks = c->num_cus * 8;
     c->extend_blocks = c->num_cus * 4;
-    if (const char* e = getenv("HPT_EXTEND_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->extend_blocks = c->num_cus * v; }
+    if (const char* e = getenv("HPT_EXTEND_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->extend_per_cu = v; }
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     *out = c;
@@ -674,6 +675,17 @@ static int default_spp_per_pass(uint64_t npix, int want) {
 }
 
 // one wavefront pass: raygen -> [extend -> shade]* -> resolve, all asynchronous on the context stream
+// Persistent grid of k_extend: as many workgroups per CU as its register budget allows (5 waves/SIMD for the linear
+// kernel, 4 for the two-level one -- hpt_kernels.hip) and as fit into the CU's 160 KB of LDS.
+static int extend_grid(const hpt_scene* s) {
+    const hpt_context* ctx = s->ctx;
+    int per_cu = ctx->extend_per_cu > 0 ? ctx->extend_per_cu : (s->ds.use_tlas ? 4 : 5);
+    const size_t lds = hptk_extend_lds_bytes(s->stack_entries, s->ds.use_tlas != 0);
+    const int fit = (int)((160u * 1024u) / std::max<size_t>(lds, 1));
+    per_cu = std::max(1, std::min(per_cu, fit));
+    return ctx->num_cus * per_cu;
+}
+
 static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks) {
     hpt_context* ctx = s->ctx;
     hipStream_t st = ctx->stream;
@@ -749,7 +761,7 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
         ps.pixel_list = pixel_list; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
         ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
         ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
-        CHK(run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, ctx->extend_blocks));
+        CHK(run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s)));
         ++passes;
         if (per_sample_host) {
             rad.resize((size_t)npix * cur * 4);
@@ -936,4 +948,4 @@ extern "C" int hpt_scene_info(hpt_scene* s, hpt_scene_info_t* out) {
 // ------------------------------------------------------------------------------------------------ tuning hooks
 // Not part of include/hpt.h: used by scripts/gpu_time.py for interleaved A/B runs inside one process.
 extern "C" void hpt_debug_set_refill(int lanes) { hptk_set_refill(lanes); }
-extern "C" void hpt_debug_set_extend_blocks(hpt_context* ctx, int per_cu) { if (ctx && per_cu >= 1 && per_cu <= 16) ctx->extend_blocks = ctx->num_cus * per_cu; }
+extern "C" void hpt_debug_set_extend_blocks(hpt_context* ctx, int per_cu) { if (ctx && per_cu >= 0 && per_cu <= 16) ctx->extend_per_cu = per_cu; }

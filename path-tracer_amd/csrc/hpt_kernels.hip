@@ -20,7 +20,7 @@
 #define PI_F 3.14159265358979323846f
 // register budgets (waves per SIMD the allocator must reach) of the two hot kernels; see DESIGN.md tuning log
 #ifndef HPT_EXTEND_WAVES
-#define HPT_EXTEND_WAVES 4
+#define HPT_EXTEND_WAVES 5       // linear-instance-list kernel: 90 VGPRs; the two-level kernel (116 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 5
@@ -236,9 +236,9 @@ __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, 
 struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 
 // ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
-//   [stack: stack_entries x HPT_BLOCK ints][node cache: 4 planes x HPT_NODE_CACHE float4][qn, qhead][queue: HPT_QUEUE_CAP uint4]
+//   [stack: stack_entries x HPT_BLOCK ints][node cache: 4 planes x HPT_NODE_CACHE float4][qn, qhead][queue: HPT_QUEUE_CAP uint2]
 struct Lds {
-    int* stack; float4* ncache; uint4* queue; unsigned* qn; unsigned* qhead; int n_cached; int refill;
+    int* stack; float4* ncache; uint2* queue; unsigned* qn; unsigned* qhead; int n_cached; int refill;
 };
 __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -247,7 +247,7 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     L.ncache = (float4*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
     L.qn = (unsigned*)(L.ncache + 4 * HPT_NODE_CACHE);
     L.qhead = L.qn + 1;
-    L.queue = (uint4*)(L.qn + 4);      // the two-level (TLAS) path launches without the queue
+    L.queue = (uint2*)(L.qn + 4);      // the two-level (TLAS) path launches without the queue
     L.n_cached = 0; L.refill = 16;
     return L;
 }
@@ -304,7 +304,7 @@ __device__ __forceinline__ bool work_slot(const WorkView& wv, uint32_t w, uint32
 
 // phase 1 for one ray: analytic instances + first mesh box entered.  Returns true when the ray must be queued.
 template <bool COUNT>
-__device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uint32_t slot, Hit& h, uint4& item, unsigned& n_inst) {
+__device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uint32_t slot, Hit& h, uint2& item, unsigned& n_inst) {
     h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
     int mpos = -1, mcount = 0;
     f3 lo0 = o, ld0 = d;
@@ -331,7 +331,7 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
             if (ok && t < h.t) { h.t = t; h.inst_side = (uint32_t)k | ((uint32_t)s << 31); }   // ascending k: earlier wins ties
         }
     }
-    if (mpos >= 0) { item = make_uint4(slot, (uint32_t)mpos, __float_as_uint(h.t), h.inst_side); return true; }
+    if (mpos >= 0) { item = make_uint2(slot, (uint32_t)mpos); return true; }   // the analytic result travels in hit[slot]
     return false;
 }
 
@@ -363,9 +363,11 @@ __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsi
                 tried = true;
                 const unsigned idx = atomicAdd(L.qhead, 1u);
                 if (idx < cnt) {
-                    const uint4 it = L.queue[idx];
+                    const uint2 it = L.queue[idx];
                     slot = it.x; mpos = first_mpos = (int)it.y;
-                    h.t = __uint_as_float(it.z); h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = it.w;
+                    // 8-byte items keep the queue at 8 KB of LDS (5 workgroups per CU fit); the best analytic hit of
+                    // phase 1 comes back from hit[] / hit_inst[] with the ray itself (same round trip, L2-resident)
+                    h.t = hit[slot].x; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = hit_inst[slot];
                     o = xyz(ray_o[slot]); d = xyz(ray_d[slot]);
                     have = true; need_setup = true;
                 }
@@ -467,11 +469,11 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
         uint32_t i;
         const bool valid = work_slot(wv, w, i);
         bool queued = false;
-        uint4 item = make_uint4(0, 0, 0, 0);
+        uint2 item = make_uint2(0, 0);
         if (valid) {
             Hit h;
             queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, h, item, n_inst);
-            if (!queued) { hit[i] = make_float4(h.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = h.inst_side; }
+            hit[i] = make_float4(h.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = h.inst_side;   // final for unqueued rays, interim otherwise
         }
         // append the queued rays: 64-bit ballot + prefix popcount, one LDS atomic per wave
         const unsigned long long mask = __ballot(queued);
@@ -711,8 +713,8 @@ k_raygen(DScene sc, DPass ps) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_extend
-template <bool COUNT>
-__global__ void __launch_bounds__(HPT_BLOCK) HPT_EXTEND_OCC
+template <bool COUNT, bool TLAS>
+__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : HPT_EXTEND_WAVES, TLAS ? 4 : HPT_EXTEND_WAVES)))
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     Lds L = lds_carve(stack_entries);
     L.refill = refill;
@@ -720,7 +722,7 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
-    if (sc.use_tlas) block_closest_hit_tlas<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    if constexpr (TLAS) block_closest_hit_tlas<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     else block_closest_hit<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
@@ -1131,7 +1133,7 @@ static inline int grid_for(uint64_t n, int max_blocks) {
 }
 // dynamic LDS of the traversal kernels: stack + node cache + work queue + queue counter (see lds_carve)
 static inline size_t trav_lds_bytes(int stack_entries, bool with_queue = true) {
-    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + 16 + (with_queue ? HPT_QUEUE_CAP * sizeof(uint4) : 0);
+    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + 16 + (with_queue ? HPT_QUEUE_CAP * sizeof(uint2) : 0);
 }
 
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
@@ -1151,12 +1153,14 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
 }
+size_t hptk_extend_lds_bytes(int stack_entries, bool tlas) { return trav_lds_bytes(stack_entries, !tlas); }
 static int g_refill = 16;
 void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
     const size_t lds = trav_lds_bytes(stack_entries, !sc.use_tlas);
-    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
+    // one kernel per (instrumented, two-level) combination: each path gets its own register allocation
+    auto k = sc.use_tlas ? (count ? k_extend<true, true> : k_extend<false, true>) : (count ? k_extend<true, false> : k_extend<false, false>);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
 }
 void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {
     const size_t tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);

@@ -1,4 +1,4 @@
-# A/B of library builds inside one GPU call: ab_variants.sh <gpu_time args> -- <variant names...> ("" = the default build)
+# A/B of library builds inside one GPU call: ab_variants.sh "<gpu_time args>" <variant names...> ("base" = the default build)
 cd $GRAFT_REPO_ROOT
 ARGS=$1; shift
 for v in "$@"; do

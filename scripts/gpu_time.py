@@ -44,7 +44,7 @@ def main():
         elif w.startswith("B"):
             for b in [int(c) for c in w[1:].split(",")]:
                 run("blocks/CU %d" % b, d, bpc=b)
-            hpt.lib.hpt_debug_set_extend_blocks(run.ctx.h, 4)
+            hpt.lib.hpt_debug_set_extend_blocks(run.ctx.h, 0)
         elif w.startswith("S"):
             run("full, spp_per_pass=%s" % w[1:], d, S=int(w[1:]))
 main()
