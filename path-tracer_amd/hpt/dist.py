@@ -44,6 +44,11 @@ class DeviceRounds:
         self.torch = torch
         self.scene, self.max_depth, self.seed, self.spp_per_pass = scene, max_depth, seed, spp_per_pass
         self.npix = scene.width * scene.height
+        # The library's kernels go on torch's CURRENT stream so that collectives between rounds are ordered after them.
+        # On the legacy default stream the handle is NULL, which would mean "the context's own stream": use a real one.
+        if torch.cuda.current_stream().cuda_stream == 0:
+            raise RuntimeError("DeviceRounds: run under `with torch.cuda.stream(torch.cuda.Stream()):` (the default stream "
+                               "has no handle to share with the library)")
         scene.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.lists = [torch.empty(self.npix, dtype=torch.int32, device="cuda") for _ in range(2)]
         self.cur = -1

@@ -170,6 +170,10 @@ def test_adaptive_rounds_api(ctx, olib, desc):
     assert info.n_instances == 9 and info.n_mesh_instances == 1 and info.n_triangles == 6320 and info.uses_tlas == 0
     assert info.n_nodes == 6319 and info.device_bytes > 6319 * 64 + 6320 * 48
     ref = sc.render(adaptive=True, initial=8, max_samples=32, max_depth=4, seed=3)
+    with pytest.raises(RuntimeError):
+        DeviceRounds(sc, max_depth=4, seed=3)          # default stream: no handle to share
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     eng = DeviceRounds(sc, max_depth=4, seed=3)
     rgb, spp = render_adaptive(eng, 0, 1, initial_samples=8, max_samples=32)
     torch.cuda.synchronize()
@@ -202,4 +206,30 @@ def test_adaptive_rounds_api(ctx, olib, desc):
     acc, mm, _ = eng.new_buffers(8)
     with pytest.raises(hpt.HptError):
         sc.render_round_device(acc.data_ptr(), mm.data_ptr(), 0, 0, spp=4, adaptive=True)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    ctx.set_stream(0)
+    sc.close()
+
+
+def test_progressive_checkpoint_resume(ctx, desc, tmp_path):
+    """checkpoint = accumulator + sample cursor: 5 + (save, new object, load) + 7 + 4 samples == one render of 16"""
+    import hpt
+    from hpt.progressive import ProgressiveRender
+    d = resized(desc, 48, 36)
+    sc = hpt.Scene(ctx, d, host_bvh=host_tree)
+    want = sc.render(spp=16, max_depth=5, seed=11)["rgb"]
+    a = ProgressiveRender(sc, max_depth=5, seed=11)
+    a.advance(5)
+    ck = str(tmp_path / "ck.npz")
+    a.save(ck)
+    b = ProgressiveRender(sc, max_depth=5, seed=11)
+    assert b.load(ck) == 5
+    b.advance(7); b.advance(4)
+    np.testing.assert_array_equal(b.image(), want)
+    c = ProgressiveRender(sc, max_depth=5, seed=12)
+    with pytest.raises(ValueError):
+        c.load(ck)
+    for r in (a, b, c):
+        r.close()
     sc.close()
