@@ -233,3 +233,29 @@ def test_progressive_checkpoint_resume(ctx, desc, tmp_path):
     for r in (a, b, c):
         r.close()
     sc.close()
+
+
+def test_full_size_properties(ctx, desc):
+    """BASELINE config-2 size (1920x1080, depth 8), where the oracle would take minutes: size-independent properties.
+    (1) linearity: doubling every emission doubles the image exactly (x2 is exact in f32, every path is unchanged);
+    (2) additivity over sample ranges: sums of samples [0,2) + [2,5) == sums of [0,5), bit for bit;
+    (3) ray accounting: primary rays = W*H*spp, bounce rays <= primary * depth, and equal between the runs."""
+    import copy
+    import torch
+    import hpt
+    d = resized(desc, 1920, 1080)
+    d2 = copy.deepcopy(d)
+    for m in d2.materials:
+        m.emission = (m.emission * np.float32(2.0)).astype(np.float32)
+    sc, sc2 = hpt.Scene(ctx, d, host_bvh=host_tree), hpt.Scene(ctx, d2, host_bvh=host_tree)
+    npix = 1920 * 1080
+    a = torch.zeros(npix * 3, device="cuda"); b = torch.zeros(npix * 3, device="cuda"); c = torch.zeros(npix * 3, device="cuda")
+    st_a = sc.render_device(a.data_ptr(), want_stats=True, spp=5, max_depth=8, seed=2)
+    st_b = sc2.render_device(b.data_ptr(), want_stats=True, spp=5, max_depth=8, seed=2)
+    assert st_a.rays_primary == npix * 5 and st_a.rays_bounce <= st_a.rays_primary * 8
+    assert (st_a.rays_primary, st_a.rays_bounce) == (st_b.rays_primary, st_b.rays_bounce)
+    assert torch.equal(a * 2.0, b) and float(a.sum()) > 0
+    sc.render_round_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=2, first_sample=0, max_depth=8, seed=2)
+    sc.render_round_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=3, first_sample=2, max_depth=8, seed=2)
+    assert torch.equal(a, c)
+    sc.close(); sc2.close()
