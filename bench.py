@@ -48,6 +48,32 @@ def recorded_traffic(kernel):
     return best
 
 
+def parity_ray_rates(scene, desc, n_gpu=10_000_000, n_cpu=1_000_000):
+    """SURVEY 8d.6 beside the frame metric: closest-hit rate of k_trace_rays on the 10 M seeded parity rays (device
+    buffers, HIP-event kernel time) and of the oracle's Mesh::intersect restatement on the first 1 M of them (host cores),
+    with the ids of those 1 M compared on the way."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    import rays as R
+    lib = ol.load(fast=True)
+    osc = ol.OracleScene(lib, desc)
+    org, dirs = R.parity_rays(osc.meshes[0].box(), n_gpu)
+    o4 = torch.zeros((n_gpu, 4), dtype=torch.float32); o4[:, :3] = torch.from_numpy(org)
+    d4 = torch.zeros((n_gpu, 4), dtype=torch.float32); d4[:, :3] = torch.from_numpy(dirs)
+    o4, d4 = o4.cuda(), d4.cuda()
+    hit = torch.zeros((n_gpu, 4), dtype=torch.float32, device="cuda"); side = torch.zeros(n_gpu, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    scene.trace_rays_device(0, n_gpu, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), side.data_ptr(), want_stats=True)
+    st = scene.trace_rays_device(0, n_gpu, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), side.data_ptr(), want_stats=True)
+    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "1024")))
+    t0 = time.perf_counter()
+    ref = osc.meshes[0].intersect(org[:n_cpu], dirs[:n_cpu], threads=threads)
+    dt = time.perf_counter() - t0
+    prim = hit[:n_cpu, 3].contiguous().view(torch.int32).cpu().numpy()
+    return {"gpu_Mrays_s": round(n_gpu / st.seconds_kernel / 1e6, 1), "gpu_rays": n_gpu, "cpu_Mrays_s": round(n_cpu / dt / 1e6, 3),
+            "cpu_rays": n_cpu, "cpu_cores": threads, "id_mismatches_in_cpu_sample": int((prim != ref["prim"]).sum())}
+
+
 def cpu_baseline(desc, spp, depth, seed):
     """The oracle (kind "port": C restatement of the reference's algorithm, faithful mode -- reference tree with loose
     boxes, no pruning, per-call matrix inversion) timed on a bounded sample of the same workload."""
@@ -206,6 +232,7 @@ def main():
             line["library_sah_tree"] = {"value": round((ast.rays_primary + ast.rays_bounce) / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt * 1e3, 3)}
             alt.close()
         if world == 1 and args.cpu_spp > 0:
+            line["parity_rays"] = parity_ray_rates(scene, desc)
             cb, cpu_img = cpu_baseline(desc, args.cpu_spp, args.depth, 1)
             line["cpu_baseline"] = cb
             # sanity: the CPU sample is the first cpu_spp samples of the same frame -> must agree with the GPU's samples 1..cpu_spp
