@@ -1,0 +1,128 @@
+"""Randomised differential test: seeded random scenes (nested transform hierarchies up to 4 levels with rotations and
+non-uniform scales, several small random meshes instanced more than once, spheres, planes, all three texture kinds,
+emitters, glossy / refractive materials, DOF cameras) through the linear instance path AND through the TLAS, against
+the oracle: closest-hit records bit-exact, images at matched samples."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from hpt import scene_io
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def rot(axis, deg):
+    c, s = F(np.cos(np.radians(deg))), F(np.sin(np.radians(deg)))
+    return {0: np.array([1, 0, 0, 0, c, s, 0, -s, c], F), 1: np.array([c, 0, -s, 0, 1, 0, s, 0, c], F), 2: np.array([c, s, 0, -s, c, 0, 0, 0, 1], F)}[axis]
+
+
+def matmul(a, b):
+    return (a.reshape(3, 3).T @ b.reshape(3, 3).T).T.reshape(9).astype(F)
+
+
+def random_xform(rng, tscale):
+    m = np.diag(rng.uniform(0.5, 1.8, 3)).astype(F).reshape(9)
+    for _ in range(int(rng.integers(0, 3))):
+        m = matmul(rot(int(rng.integers(0, 3)), rng.uniform(-180, 180)), m)
+    return m, rng.uniform(-tscale, tscale, 3).astype(F)
+
+
+def random_mesh(rng, n):
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    v = (c + rng.uniform(-0.35, 0.35, (n, 3, 3))).reshape(-1, 3).astype(F)
+    tris = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    nrm = rng.normal(size=(3 * n, 3)); nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(F)
+    uvw = np.concatenate([rng.random((3 * n, 2)), np.zeros((3 * n, 1))], axis=1).astype(F)
+    return scene_io.Mesh(verts=v, tris=tris, normals=nrm, ntris=tris.copy(), uvw=uvw, ttris=tris.copy())
+
+
+def random_texture(rng, n_images):
+    kind = int(rng.integers(0, 3))
+    col = rng.uniform(0.1, 0.9, 3).astype(F)
+    m, t = random_xform(rng, 0.5)
+    if kind == 1:
+        return scene_io.Texture(kind=1, color=col, color1=rng.random(3).astype(F), color2=rng.random(3).astype(F), m=m, t=t)
+    if kind == 2:
+        return scene_io.Texture(kind=2, image=int(rng.integers(0, n_images)), color=col, m=m, t=t)
+    return scene_io.tex_color(col)
+
+
+def random_scene(seed, w=56, h=40):
+    rng = np.random.default_rng(seed)
+    d = scene_io.SceneDesc()
+    for _ in range(2):
+        d.images.append(rng.integers(0, 256, size=(int(rng.integers(3, 9)), int(rng.integers(3, 9)), 3), dtype=np.uint8))
+    for k in range(6):
+        kind = rng.random()
+        mat = scene_io.Material(name="m%d" % k, diffuse=random_texture(rng, 2))
+        if kind < 0.3:
+            mat.reflection = random_texture(rng, 2); mat.reflection_glossiness = float(rng.uniform(0, 0.3))
+        elif kind < 0.55:
+            mat.diffuse = scene_io.tex_color((0.05, 0.05, 0.05)); mat.refraction = random_texture(rng, 2)
+            mat.refraction_index = float(rng.uniform(1.1, 1.7)); mat.refraction_glossiness = float(rng.uniform(0, 0.1))
+        if rng.random() < 0.35:
+            mat.emission = rng.uniform(0.5, 4, 3).astype(F)
+        d.materials.append(mat)
+    for _ in range(int(rng.integers(1, 4))):
+        d.meshes.append(random_mesh(rng, int(rng.integers(20, 300))))
+
+    def add(parent, depth):
+        geom = int(rng.choice([0, 1, 2, 3], p=[0.25, 0.3, 0.15, 0.3])) if depth < 3 else int(rng.choice([1, 2, 3]))
+        m, t = random_xform(rng, 3.0 if depth == 0 else 1.5)
+        d.nodes.append(scene_io.Node(parent=parent, geom=geom, mesh=int(rng.integers(0, len(d.meshes))) if geom == 3 else -1,
+                                     material=int(rng.integers(0, 6)) if geom else -1, m=m, t=t))
+        me = len(d.nodes) - 1
+        if depth < 3:
+            for _ in range(int(rng.integers(0, 3)) if geom else int(rng.integers(1, 4))):
+                if len(d.nodes) < 22:
+                    add(me, depth + 1)
+    while len(d.nodes) < 12:
+        add(-1, 0)
+    d.nodes.append(scene_io.Node(parent=-1, geom=2, mesh=-1, material=0, m=(np.eye(3).reshape(9) * 12).astype(F), t=np.array([0, 0, -4], F)))
+    d.background = random_texture(rng, 2)
+    d.environment = random_texture(rng, 2)
+    pos = np.array([0, -11, 3], F) + rng.uniform(-1, 1, 3).astype(F)
+    dr = scene_io.normalize((np.zeros(3, F) - pos).astype(F))
+    d.camera = scene_io.Camera(pos=pos, dir=dr, up=scene_io.cross(scene_io.cross(dr, np.array([0, 0, 1], F)), dr), fov=45.0, width=w, height=h,
+                               focaldist=float(rng.uniform(5, 12)), dof=float(rng.choice([0.0, 0.08])))
+    return d
+
+
+def probe_rays(osc, d, n, seed):
+    rng = np.random.default_rng(seed)
+    cam = d.camera
+    pr = [osc.primary_ray(int(x), int(y), 1 + int(k), 7) for x, y, k in zip(rng.integers(0, cam.width, n // 2), rng.integers(0, cam.height, n // 2), rng.integers(0, 16, n // 2))]
+    o = np.array([p[0] for p in pr], F); dd = np.array([p[1] for p in pr], F)
+    h = osc.intersect(o, dd)
+    ok = h["node"] >= 0
+    o2 = (h["pos"][ok] + F(0.01) * h["normal"][ok]).astype(F)
+    d2 = rng.normal(size=o2.shape); d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(F)
+    o3 = rng.uniform(-4, 4, (n // 4, 3)).astype(F); d3 = rng.normal(size=(n // 4, 3)).astype(F)
+    return np.concatenate([o, o2, o3]), np.concatenate([dd, d2, d3])
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+@pytest.mark.parametrize("tlas", [False, True])
+def test_random_scene(ctx, olib, seed, tlas, monkeypatch):
+    import hpt
+    d = random_scene(seed)
+    monkeypatch.setenv("HPT_TLAS_MIN", "2" if tlas else "1000000")
+    osc = ol.OracleScene(olib, d)
+    gsc = hpt.Scene(ctx, d)
+    assert gsc.info().uses_tlas == int(tlas)
+    o, dd = probe_rays(osc, d, 6000, seed)
+    g, r = gsc.intersect(o, dd), osc.intersect(o, dd)
+    # random triangle soups intersect each other: exact-equal t between different triangles does not occur, so every
+    # field must agree bit for bit; sphere uv within 2 ulp (atan2f/asinf)
+    for k in ("node", "prim", "t", "side", "pos", "normal"):
+        np.testing.assert_array_equal(g[k], r[k], err_msg=k)
+    np.testing.assert_allclose(g["uvw"], r["uvw"], rtol=0, atol=5e-7)
+    assert (r["node"] >= 0).mean() > 0.5
+    ref = osc.render(spp=6, max_depth=5, seed=seed, want_samples=True)
+    got = gsc.render_samples(spp=6, max_depth=5, seed=seed)
+    rel = np.abs(got - ref["per_sample"]).max(axis=2) / (np.abs(ref["per_sample"]).max(axis=2) + 1e-3)
+    assert (rel <= 1e-3).mean() >= 0.99, (rel <= 1e-3).mean()
+    img = gsc.render(spp=6, max_depth=5, seed=seed)
+    assert float(np.sqrt(((img["rgb"] - ref["rgb"]) ** 2).mean()) / max(ref["rgb"].mean(), 1e-6)) <= 2e-2
+    gsc.close()
