@@ -243,6 +243,7 @@ Mesh load_obj(const std::string& path) {
                 vi = vi > 0 ? vi - 1 : (long)(m.verts.size() / 3) + vi;
                 ti = ti > 0 ? ti - 1 : (long)(m.uvw.size() / 3) + ti;
                 ni = ni > 0 ? ni - 1 : (long)(m.normals.size() / 3) + ni;
+                if (vi < 0 || ti < 0 || ni < 0 || vi > 0x7fffffffL || ti > 0x7fffffffL || ni > 0x7fffffffL) throw Error("obj: face index out of range");
                 idx.push_back({vi, ti, ni});
             }
             if (idx.size() < 3) continue;   // points / lines are not Primitive::Triangle (load.rs:301)
@@ -256,6 +257,11 @@ Mesh load_obj(const std::string& path) {
         }
     }
     if (m.verts.empty()) throw Error("no objects found in file");   // load.rs:278
+    // the reference indexes its Vecs with these (geometry.rs:117-130, :226): out of range is a panic there
+    auto check = [](const std::vector<uint32_t>& idx, size_t n, const char* what) {
+        for (uint32_t i : idx) if ((size_t)i >= n) throw Error(std::string("obj: ") + what + " index out of range");
+    };
+    check(m.tris, m.verts.size() / 3, "vertex"); check(m.ntris, m.normals.size() / 3, "normal"); check(m.ttris, m.uvw.size() / 3, "texture vertex");
     return m;
 }
 

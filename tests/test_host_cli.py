@@ -164,3 +164,19 @@ def test_cli_renders_same_png(ctx, desc, tmp_path):
         want = hpt.tonemap_rgba8(sc.render(**kw)["rgb"])
         np.testing.assert_array_equal(img, want[:, :, :3])
     sc.close()
+
+
+def test_cli_rejects_bad_obj_indices(tmp_path):
+    """out-of-range / zero / overflowing face indices: the reference panics when it indexes its Vecs; the C++ host must
+    not read out of bounds (found by mutation fuzzing under ASan)"""
+    import shutil
+    shutil.copy(os.path.join(GOLDEN, "scene.xml"), str(tmp_path / "scene.xml"))
+    lines = open(os.path.join(GOLDEN, "teapot.obj")).read().split("\n")
+    k = next(i for i, l in enumerate(lines) if l.startswith("f "))
+    for bad in ("999999/1/1", "0/1/1", "1/999999/1", "1/1/-999999", "4294967297/1/1"):
+        toks = lines[k].split()
+        mutated = list(lines)
+        mutated[k] = " ".join([toks[0], bad] + toks[2:])
+        (tmp_path / "teapot.obj").write_text("\n".join(mutated))
+        r = subprocess.run([CLI, "--dump-scene", str(tmp_path / "o.txt"), str(tmp_path / "scene.xml")], capture_output=True, text=True)
+        assert r.returncode == 101 and "index out of range" in r.stderr, (bad, r.returncode, r.stderr)
