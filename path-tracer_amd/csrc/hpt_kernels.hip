@@ -991,21 +991,24 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                         p_refraction = p_refraction / p_range;
                         const float rnd = rng_f32(key, d0 + 1);
                         const float ra = rng_f32(key, d0 + 2), rb = rng_f32(key, d0 + 3);
-                        f3 new_dir = mk3(0, 0, 0), albedo = mk3(0, 0, 0); float p = 0.0f; bool picked = true;
+                        // the three lobes only choose (axis, z); the expensive cone sample (sincosf, asinf, three
+                        // normalisations) runs ONCE after the divergent part instead of once per lobe present in the wave
+                        f3 axis = normal, albedo = mk3(0, 0, 0); float z = ra, p = 0.0f; bool picked = true;
                         if (rnd < p_diffuse) {
-                            new_dir = sample_about(normal, ra, rb);
-                            albedo = diffuse; p = p_diffuse;
+                            albedo = diffuse; p = p_diffuse;                       // scene.rs:413-429: hemisphere, z_min = 0
                         } else if (rnd < p_diffuse + p_reflection) {
                             const float z_min = cosf(mat.refl_gloss);
-                            new_dir = sample_about(reflect_ray(neg3(d), normal), z_min + ra * (1.0f - z_min), rb);
+                            axis = reflect_ray(neg3(d), normal); z = z_min + ra * (1.0f - z_min);
                             albedo = reflection; p = p_reflection;
                         } else if (rnd < p_diffuse + p_reflection + p_refraction) {
                             f3 rd;
                             if (!refract_ray(neg3(d), normal, n1, n2, rd)) rd = reflect_ray(neg3(d), normal);
                             const float z_min = cosf(mat.refr_gloss);
-                            new_dir = sample_about(rd, z_min + ra * (1.0f - z_min), rb);
+                            axis = rd; z = z_min + ra * (1.0f - z_min);
                             albedo = refraction; p = p_refraction;
                         } else picked = false;
+                        f3 new_dir = mk3(0, 0, 0);
+                        if (picked) new_dir = sample_about(axis, z, rb);
                         if (picked) {
                             const float ndot = dot3(normal, new_dir);
                             // f = n.dot(new_dir) * albedo / p   (scene.rs:172,176,180)
