@@ -193,8 +193,8 @@ def main():
         crays = cst.rays_primary + cst.rays_bounce
         info = scene.info()
         inst_bytes = 128.0 * cst.inst_tests if info.uses_tlas else 0.0
-        bytes_per_ray = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested + inst_bytes) / crays + EXTEND_QUEUE_BYTES
-        bvh_bytes_per_ray = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested) / crays
+        bytes_per_ray = (info.node_bytes * float(cst.nodes_visited) + 48.0 * cst.tris_tested + inst_bytes) / crays + EXTEND_QUEUE_BYTES
+        bvh_bytes_per_ray = (info.node_bytes * float(cst.nodes_visited) + 48.0 * cst.tris_tested) / crays
 
     if rank == 0:
         achieved = bytes_per_ray * rays_local / ext_s_local

@@ -114,6 +114,8 @@ typedef struct {               /* what hpt_scene_commit laid out in HBM */
     int32_t uses_tlas, stack_entries;
     int64_t n_triangles;
     uint64_t device_bytes;     /* scene data resident in HBM (render workspaces excluded) */
+    int32_t node_bytes;        /* 32: 16-bit child boxes (default when the grid resolves the leaves), 64: float boxes */
+    int32_t reserved;
 } hpt_scene_info_t;
 
 /* ---- misc ---- */

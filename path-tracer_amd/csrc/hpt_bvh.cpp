@@ -208,3 +208,58 @@ bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_
     }
     return true;
 }
+
+// ------------------------------------------------------------------------------------------------ Node32
+QuantFrame quant_frame(const FlatMesh& fm) {
+    QuantFrame f;
+    double ext[3], maxext = 0.0;
+    for (int k = 0; k < 3; ++k) { ext[k] = (double)fm.bmax[k] - (double)fm.bmin[k]; maxext = std::max(maxext, ext[k]); }
+    f.quantum = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        // coordinates of the tree map to [8, 65527]: room for the outward rounding without clamping
+        const double e = std::max({ext[k], 1e-5 * maxext, 1e-20});
+        const double s = e / (65535.0 - 16.0);
+        f.scale[k] = (float)s;
+        if ((double)f.scale[k] < s) f.scale[k] = std::nextafterf(f.scale[k], INFINITY);   // never shrink the grid
+        f.base[k] = (float)((double)fm.bmin[k] - 8.0 * (double)f.scale[k]);
+        if ((double)f.base[k] > (double)fm.bmin[k] - 8.0 * (double)f.scale[k]) f.base[k] = std::nextafterf(f.base[k], -INFINITY);
+        f.quantum = std::max(f.quantum, (double)f.scale[k]);
+    }
+    // mean extent (largest axis) of the leaf boxes = the child boxes that belong to triangle refs
+    double sum = 0.0; size_t n = 0;
+    for (int32_t i = 0; i < fm.n_interior; ++i) {
+        const float* q = &fm.nodes[(size_t)i * 16];
+        int32_t refs[2]; std::memcpy(&refs[0], &q[3], 4); std::memcpy(&refs[1], &q[7], 4);
+        for (int c = 0; c < 2; ++c) if (refs[c] < 0) {
+            const float* mn = q + 8 * c; const float* mx = q + 8 * c + 4;
+            sum += std::max({(double)mx[0] - mn[0], (double)mx[1] - mn[1], (double)mx[2] - mn[2]}); ++n;
+        }
+    }
+    f.mean_leaf_extent = n ? sum / (double)n : maxext;
+    return f;
+}
+
+bool quantize_nodes(const float* nodes64, int32_t n_interior, const QuantFrame& f, std::vector<uint32_t>& out, std::string& err) {
+    out.assign((size_t)n_interior * 8, 0u);
+    for (int32_t i = 0; i < n_interior; ++i) {
+        const float* q = nodes64 + (size_t)i * 16;
+        uint32_t* w = &out[(size_t)i * 8];
+        std::memcpy(&w[3], &q[3], 4); std::memcpy(&w[7], &q[7], 4);
+        for (int c = 0; c < 2; ++c) {
+            const float* mn = q + 8 * c; const float* mx = q + 8 * c + 4;
+            for (int k = 0; k < 3; ++k) {
+                if (!(mn[k] <= mx[k])) { err = "bvh: empty or NaN child box cannot be quantised"; return false; }
+                const double lo = std::floor(((double)mn[k] - (double)f.base[k]) / (double)f.scale[k]) - 1.0;
+                const double hi = std::ceil(((double)mx[k] - (double)f.base[k]) / (double)f.scale[k]) + 1.0;
+                if (lo < 0.0 || hi > 65535.0) { err = "bvh: child box outside the quantisation grid"; return false; }
+                const uint32_t ql = (uint32_t)lo, qh = (uint32_t)hi;
+                // what the device computes at worst: an f32 fma of the same decode
+                if (std::fmaf((float)ql, f.scale[k], f.base[k]) > mn[k] || std::fmaf((float)qh, f.scale[k], f.base[k]) < mx[k]) {
+                    err = "bvh: quantised child box does not contain the original"; return false;
+                }
+                w[4 * c + k] = ql | (qh << 16);
+            }
+        }
+    }
+    return true;
+}

@@ -32,3 +32,13 @@ bool flatten_tree(const HostTree& tree, const float* leaf_boxes, int32_t nleaf, 
 // Tight refit + breadth-first renumbering + packing.  Child refs are LOCAL to the mesh; the caller rebases them.
 bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_idx, const float* normals, const uint32_t* nrm_idx,
                   const float* uvw, const uint32_t* uv_idx, int32_t ntri, FlatMesh& out, std::string& err);
+
+// ---- Node32: the same tree with 16-bit child boxes on a per-tree grid (2 quads per node instead of 4) ----
+// word layout of one node (8 x uint32): {Lx, Ly, Lz, refL, Rx, Ry, Rz, refR} with each box word = min | max << 16.
+// A coordinate decodes to qbase + q * qscale; boxes only ever GROW (min rounded down, max rounded up, one more
+// quantum on each side for the f32 decode), so culling stays conservative and hits are unchanged.
+struct QuantFrame { float base[3], scale[3]; double mean_leaf_extent, quantum; };
+// grid over [bmin, bmax] of the tree; mean_leaf_extent / quantum tell the caller whether 16 bits resolve the leaves
+QuantFrame quant_frame(const FlatMesh& fm);
+// nodes64: n_interior * 16 floats (refs already in place) -> n_interior * 8 words; false if a box fails the decode check
+bool quantize_nodes(const float* nodes64, int32_t n_interior, const QuantFrame& f, std::vector<uint32_t>& out, std::string& err);

@@ -7,6 +7,11 @@
 //            child ref >= 0: index of an interior node (global over all meshes), < 0: ~(global triangle index).
 //            Leaves (bvh.rs:19-22) carry exactly one primitive, so they are folded into their parent's refs.
 //            Interior nodes of one mesh are stored in breadth-first order (top levels first => cacheable prefix).
+//   Node32 : the same record with 16-bit child boxes on a per-tree grid, 2 x uint4 = 32 bytes (default when the grid
+//            resolves the leaves; halves the per-lane fetches of a traversal step -- the texture addresser, not bytes,
+//            limits the divergent node fetch):
+//            q0 = (Lx, Ly, Lz, left_ref)  q1 = (Rx, Ry, Rz, right_ref), box word = min | max << 16, coordinate =
+//            qbase + q * qscale (DMesh / DScene.tlas_*); boxes are rounded outward, so culling stays conservative.
 //   Tri48  : 3 x float4 per triangle: (a.xyz,0) (b-a,0) (c-a,0)  -- the operands of geometry.rs:188-199
 //   TriShade: 7 x float4 per triangle: a,b,c (get_point), n0,n1,n2 (get_normal), t0,t1,t2 (get_texture_vertex),
 //            27 floats + 1 pad, fetched once per closest hit by the shade stage only.
@@ -19,7 +24,6 @@
 #define HPT_TRISHADE_QUADS 7
 #define HPT_MISS_INST 0x7fffffffu
 #define HPT_MAX_DEPTH_LIMIT 64   // max bounces (size of the per-depth live-count array)
-#define HPT_NODE_CACHE 0         // interior nodes staged in LDS per workgroup (breadth-first prefix of the node array)
 #ifndef HPT_SHARDS
 #define HPT_SHARDS 64
 #endif
@@ -39,7 +43,7 @@ struct DMesh {
     int32_t ntri;
     int32_t stack_need;   // traversal stack entries needed (tree depth + 1)
     float bmin[3], bmax[3];   // tight root box
-    int32_t pad[2];
+    float qbase[3], qscale[3];   // Node32 grid of this mesh's tree
 };
 
 // one level of the Node chain of an instance (scene.rs:102-105 Transform), rows of 3x3 matrices as float4
@@ -94,6 +98,8 @@ struct DScene {
     const uint8_t* image_pool;
     int32_t n_instances, n_meshes, n_mesh_instances, n_nodes;
     int32_t use_tlas, tlas_root;     // two-level traversal (many instances): ref of the TLAS root in nodes[]
+    int32_t node32, pad0;            // 1: nodes[] holds Node32 records (2 quads per node), 0: Node64 (4 quads)
+    float tlas_qbase[3], tlas_qscale[3];   // Node32 grid of the TLAS
     DTexture background, environment;
     DCamera cam;
 };

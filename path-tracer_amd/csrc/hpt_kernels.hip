@@ -155,24 +155,61 @@ __device__ __forceinline__ bool intersect_plane(f3 pos, f3 dir, float& t, int& s
 }
 
 // ------------------------------------------------------------------------------------------------ BVH traversal
-struct RayBox { float idx, idy, idz, oxi, oyi, ozi; };
+// Slab form of a ray for box tests: the ray parameter where it crosses the plane {axis = c} is t(c) = c * a + b.
+// For float coordinates a = 1/d, b = -o/d; for Node32's 16-bit coordinates (c = qbase + q * qscale) the grid folds
+// into the coefficients: t(q) = q * (qscale * a) + (qbase * a + b), so a quantised box costs the same 12 fma.
+struct Slab { float ax, ay, az, bx, by, bz; };
+typedef Slab RayBox;
 __device__ __forceinline__ float safe_dir(float v) { return fabsf(v) < 1.0e-30f ? copysignf(1.0e-30f, v) : v; }
-__device__ __forceinline__ RayBox make_raybox(f3 o, f3 d) {
-    RayBox r;
-    r.idx = 1.0f / safe_dir(d.x); r.idy = 1.0f / safe_dir(d.y); r.idz = 1.0f / safe_dir(d.z);
-    r.oxi = o.x * r.idx; r.oyi = o.y * r.idy; r.ozi = o.z * r.idz;
+__device__ __forceinline__ Slab make_raybox(f3 o, f3 d) {
+    Slab r;
+    r.ax = 1.0f / safe_dir(d.x); r.ay = 1.0f / safe_dir(d.y); r.az = 1.0f / safe_dir(d.z);
+    r.bx = -(o.x * r.ax); r.by = -(o.y * r.ay); r.bz = -(o.z * r.az);
     return r;
+}
+__device__ __forceinline__ Slab quant_slab(const Slab& s, const float* qbase, const float* qscale) {
+    Slab q;
+    q.ax = qscale[0] * s.ax; q.ay = qscale[1] * s.ay; q.az = qscale[2] * s.az;
+    q.bx = __builtin_fmaf(qbase[0], s.ax, s.bx); q.by = __builtin_fmaf(qbase[1], s.ay, s.by); q.bz = __builtin_fmaf(qbase[2], s.az, s.bz);
+    return q;
 }
 // slab test (bvh.rs:225-281 semantics + the two culls the reference lacks: box behind the origin, box beyond bound).
 // It never decides a hit: boxes are supersets of their triangles and the relative slack (1e-6 on tout and on the
 // bound) keeps the fma/reciprocal form from culling a box the reference's divide form (bvh.rs:233-234) enters.
-__device__ __forceinline__ bool box_hit(const RayBox& rb, float3 bmin, float3 bmax, float bound, float& tin) {
-    float t0x = __builtin_fmaf(bmin.x, rb.idx, -rb.oxi), t1x = __builtin_fmaf(bmax.x, rb.idx, -rb.oxi);
-    float t0y = __builtin_fmaf(bmin.y, rb.idy, -rb.oyi), t1y = __builtin_fmaf(bmax.y, rb.idy, -rb.oyi);
-    float t0z = __builtin_fmaf(bmin.z, rb.idz, -rb.ozi), t1z = __builtin_fmaf(bmax.z, rb.idz, -rb.ozi);
+__device__ __forceinline__ bool slab_hit(float t0x, float t1x, float t0y, float t1y, float t0z, float t1z, float bound, float& tin) {
     tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
     const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * 1.000001f;
     return (tin <= tout) && (tout >= 0.0f) && (tin <= bound * 1.000001f);
+}
+__device__ __forceinline__ bool box_hit(const Slab& rb, float3 bmin, float3 bmax, float bound, float& tin) {
+    return slab_hit(__builtin_fmaf(bmin.x, rb.ax, rb.bx), __builtin_fmaf(bmax.x, rb.ax, rb.bx),
+                    __builtin_fmaf(bmin.y, rb.ay, rb.by), __builtin_fmaf(bmax.y, rb.ay, rb.by),
+                    __builtin_fmaf(bmin.z, rb.az, rb.bz), __builtin_fmaf(bmax.z, rb.az, rb.bz), bound, tin);
+}
+// 16-bit box word = min | max << 16 along one axis
+__device__ __forceinline__ bool qbox_hit(const Slab& qs, uint32_t wx, uint32_t wy, uint32_t wz, float bound, float& tin) {
+    return slab_hit(__builtin_fmaf((float)(wx & 0xffffu), qs.ax, qs.bx), __builtin_fmaf((float)(wx >> 16), qs.ax, qs.bx),
+                    __builtin_fmaf((float)(wy & 0xffffu), qs.ay, qs.by), __builtin_fmaf((float)(wy >> 16), qs.ay, qs.by),
+                    __builtin_fmaf((float)(wz & 0xffffu), qs.az, qs.bz), __builtin_fmaf((float)(wz >> 16), qs.az, qs.bz), bound, tin);
+}
+// One interior node: fetch the record (Node64: 4 quads, Node32: 2) and test both child boxes against the lane's slab
+// (`ns` must be the quantised slab of the tree's grid for Node32).
+template <bool NODE32>
+__device__ __forceinline__ void test_children(const float4* __restrict__ nodes, int ref, const Slab& ns, float bound,
+                                              bool& hitL, bool& hitR, float& tinL, float& tinR, int& l, int& r) {
+    if constexpr (NODE32) {
+        const uint4* nq = (const uint4*)nodes + (uint32_t)ref * 2u;
+        const uint4 q0 = nq[0], q1 = nq[1];
+        hitL = qbox_hit(ns, q0.x, q0.y, q0.z, bound, tinL);
+        hitR = qbox_hit(ns, q1.x, q1.y, q1.z, bound, tinR);
+        l = (int)q0.w; r = (int)q1.w;
+    } else {
+        const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
+        const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+        hitL = box_hit(ns, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound, tinL);
+        hitR = box_hit(ns, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound, tinR);
+        l = __float_as_int(q0.w); r = __float_as_int(q1.w);
+    }
 }
 
 // Closest hit of one ray against one mesh (geometry.rs:132-158 + bvh.rs:148-204).
@@ -180,36 +217,25 @@ __device__ __forceinline__ bool box_hit(const RayBox& rb, float3 bmin, float3 bm
 //    replace the scene-level nearest: t < tlimit, or t == tlimit when this instance comes EARLIER in the reference's
 //    visiting order than the holder of tlimit (tie_ok; scene.rs:196,251 keep the earlier node on equal t)
 //  - stk: this lane's column of the LDS stack (stride HPT_BLOCK ints)
-//  - ncache: LDS copy of the first n_cached Node64 records, one plane per quad (plane stride HPT_NODE_CACHE)
-template <bool COUNT>
-__device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                              const float4* ncache, int n_cached,
-                                              int root_ref, f3 o, f3 d, float tlimit, bool tie_ok,
+template <bool COUNT, bool NODE32>
+__device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, const float4* __restrict__ tris, const DMesh& mesh,
+                                              f3 o, f3 d, float tlimit, bool tie_ok,
                                               float& tm, int& prim, float& bu, float& bv, int& side,
                                               int* stk, unsigned& n_int, unsigned& n_tri) {
-    const RayBox rb = make_raybox(o, d);
+    const Slab rb = make_raybox(o, d);
+    const Slab ns = NODE32 ? quant_slab(rb, mesh.qbase, mesh.qscale) : rb;
     const int SENTINEL = (int)0x80000000;      // bottom of the stack: a "leaf" ref no triangle can have
     stk[0] = SENTINEL;
     int sp = 1;
-    int ref = root_ref;
+    int ref = mesh.root_ref;
     // if-if loop.  (A while-while loop -- inner loop over interior nodes until every lane holds a leaf -- measured 47 %
     // SLOWER here: leaves hold one triangle, so lanes that reach a leaf early idle; a reciprocal pre-filter in front of the
     // triangle test's three IEEE divisions measured +-0: see DESIGN.md tuning log.)
     while (ref != SENTINEL) {
         if (ref >= 0) {
-            float4 q0, q1, q2, q3;
-            if (ref < n_cached) {
-                q0 = ncache[ref]; q1 = ncache[HPT_NODE_CACHE + ref]; q2 = ncache[2 * HPT_NODE_CACHE + ref]; q3 = ncache[3 * HPT_NODE_CACHE + ref];
-            } else {
-                const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
-                q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3];
-            }
             if (COUNT) n_int++;
-            const float bound = fminf(tm, tlimit);
-            float tinL, tinR;
-            const bool hitL = box_hit(rb, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound, tinL);
-            const bool hitR = box_hit(rb, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound, tinR);
-            const int l = __float_as_int(q0.w), r = __float_as_int(q1.w);
+            bool hitL, hitR; float tinL, tinR; int l, r;
+            test_children<NODE32>(nodes, ref, ns, fminf(tm, tlimit), hitL, hitR, tinL, tinR, l, r);
             if (hitL && hitR) {
                 const bool lfirst = tinL < tinR;
                 stk[sp * HPT_BLOCK] = lfirst ? r : l;
@@ -236,57 +262,22 @@ __device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, 
 struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 
 // ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
-//   [stack: stack_entries x HPT_BLOCK ints][node cache: 4 planes x HPT_NODE_CACHE float4][qn, qhead][queue: HPT_QUEUE_CAP uint2]
+//   [stack: stack_entries x HPT_BLOCK ints][qn, qhead][queue: HPT_QUEUE_CAP uint2]
+// (an LDS copy of the top tree levels was tried twice -- 16..1024 nodes -- and was 5 % slower each time: the second, LDS-side
+//  wait per step costs more than the fetches it saves)
 struct Lds {
-    int* stack; float4* ncache; uint2* queue; unsigned* qn; unsigned* qhead; int n_cached; int refill;
+    int* stack; uint2* queue; unsigned* qn; unsigned* qhead; int refill;
 };
 __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L;
     L.stack = (int*)lds_raw;
-    L.ncache = (float4*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
-    L.qn = (unsigned*)(L.ncache + 4 * HPT_NODE_CACHE);
+    L.qn = (unsigned*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
     L.qhead = L.qn + 1;
     L.queue = (uint2*)(L.qn + 4);      // the two-level (TLAS) path launches without the queue
-    L.n_cached = 0; L.refill = 16;
+    L.refill = 16;
     return L;
 }
-// stage the breadth-first prefix of the node array (the top levels of the first mesh's tree) into LDS
-__device__ __forceinline__ void lds_load_nodes(Lds& L, const float4* __restrict__ nodes, int n_nodes) {
-    // HPT_NODE_CACHE == 0 disables the cache: a second, LDS-side wait per step cost more than the L2 latency it saved
-    L.n_cached = n_nodes < HPT_NODE_CACHE ? n_nodes : HPT_NODE_CACHE;
-    for (int j = threadIdx.x; j < 4 * L.n_cached; j += HPT_BLOCK) L.ncache[(j & 3) * HPT_NODE_CACHE + (j >> 2)] = nodes[j];
-    __syncthreads();
-}
-
-// Mesh part of scene.rs:190-208 for one ray: mesh instances mesh_instances[mpos..] in visiting order, starting from
-// the best hit found so far.
-template <bool COUNT>
-__device__ __forceinline__ void trace_mesh_instances(const DScene& sc, const Lds& L, int* stk, f3 o, f3 d, int mpos, Hit& h,
-                                                     unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
-    for (int m = mpos; m < sc.n_mesh_instances; ++m) {
-        const int i = sc.mesh_instances[m];
-        const DInstance* in = sc.instances + i;
-        f3 lo = o, ld = d;
-        ray_level(in->lv[0], lo, ld);
-        const int nlev = in->xf_count;
-        if (nlev > 1) {
-            ray_level(in->lv[1], lo, ld);
-            for (int k = 2; k < nlev; ++k) ray_level(sc.xinv[in->xf_first + k], lo, ld);
-        }
-        if (COUNT && m > mpos) n_inst++;   // the first one was already counted by the analytic phase
-        const DMesh* mesh = sc.meshes + in->mesh;
-        const RayBox rb = make_raybox(lo, ld);
-        float tin;
-        if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
-            float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, s = 0;
-            const bool tie_ok = (uint32_t)i < (h.inst_side & 0x7fffffffu);
-            traverse_mesh<COUNT>(sc.nodes, sc.tris, L.ncache, L.n_cached, mesh->root_ref, lo, ld, h.t, tie_ok, tm, prim, bu, bv, s, stk, n_int, n_tri);
-            if (prim >= 0) { h.t = tm; h.u = bu; h.v = bv; h.prim = prim; h.inst_side = (uint32_t)i | ((uint32_t)s << 31); }
-        }
-    }
-}
-
 // Sharded wavefront queues.  A queue of capacity shards*cap slots is split into `shards` segments; segment s holds
 // counts[s] live entries in slots [s*cap, s*cap+counts[s]).  Work item w of a kernel = chunk (w / shards) of segment
 // (w % shards); a persistent workgroup takes w = blockIdx.x, + gridDim.x, ...  Producers append to the segment they
@@ -340,7 +331,7 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
 // the final hit record.  The inner loop is nothing but traversal steps; the wave leaves it as soon as L.refill lanes
 // have finished their mesh, merges their results and hands them the next queued ray (node visits per ray are
 // heavy-tailed, 20..300: without the refill a wave runs as long as its slowest ray with most lanes idle).
-template <bool COUNT>
+template <bool COUNT, bool NODE32>
 __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsigned cnt, const float4* __restrict__ ray_o,
                                             const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                             unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
@@ -403,6 +394,7 @@ __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsi
                 rb = make_raybox(lo, ld);
                 float tin;
                 if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
+                    if (NODE32) rb = quant_slab(rb, mesh->qbase, mesh->qscale);   // from here on rb addresses the tree's 16-bit grid
                     tm = HPT_INF; prim = -1; bu = 0.0f; bv = 0.0f; side = 0;
                     tie_ok = (uint32_t)inst_idx < (h.inst_side & 0x7fffffffu);
                     stk[0] = SENTINEL; sp = 1; ref = mesh->root_ref;
@@ -418,14 +410,9 @@ __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsi
             // (gating the triangle block on ">= K lanes wait at a leaf" measured +-1 % for K = 2..8 and slower above:
             // what it saves in instructions it loses in idle lanes)
             if (ref >= 0) {
-                const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
-                const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
                 if (COUNT) n_int++;
-                const float bound = fminf(tm, h.t);
-                float tinL, tinR;
-                const bool hitL = box_hit(rb, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound, tinL);
-                const bool hitR = box_hit(rb, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound, tinR);
-                const int l = __float_as_int(q0.w), r = __float_as_int(q1.w);
+                bool hitL, hitR; float tinL, tinR; int l, r;
+                test_children<NODE32>(nodes, ref, rb, fminf(tm, h.t), hitL, hitR, tinL, tinR, l, r);
                 if (hitL && hitR) {
                     const bool lfirst = tinL < tinR;
                     stk[sp * HPT_BLOCK] = lfirst ? r : l;
@@ -457,7 +444,7 @@ __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsi
 //          root-box test of the mesh instances; a ray that enters a mesh box is queued in LDS instead of traversed
 //  phase 2 (whenever HPT_BLOCK rays are queued): one queued ray per lane -> every lane of every wave walks a BVH
 //  Rays are identified by their slot i; results go to hit[i] / hit_inst[i] exactly once per ray.
-template <bool COUNT>
+template <bool COUNT, bool NODE32>
 __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
                                                   const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                   unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
@@ -486,14 +473,14 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
         __syncthreads();
         const unsigned cnt = *L.qn;
         if (cnt > HPT_QUEUE_CAP - HPT_BLOCK) {      // the next chunk might not fit: drain everything (workgroup-uniform)
-            drain_queue<COUNT>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
+            drain_queue<COUNT, NODE32>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
             __syncthreads();
             if (threadIdx.x == 0) { *L.qn = 0; *L.qhead = 0; }
             __syncthreads();
         }
     }
     const unsigned cnt = *L.qn;
-    if (cnt) drain_queue<COUNT>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
+    if (cnt) drain_queue<COUNT, NODE32>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
 }
 
 // ------------------------------------------------------------------------------------------------ two-level traversal
@@ -505,7 +492,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
 // smaller, which is the reference's rule "strictly nearer wins, earlier node wins ties" (scene.rs:196,251).
 #define HPT_INST_BASE 0x40000000
 #define HPT_REF_RESTORE ((int)~0x7ffffffe)
-template <bool COUNT>
+template <bool COUNT, bool NODE32>
 __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, uint32_t base_slot, uint32_t n_valid,
                                                 const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                 float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
@@ -535,6 +522,7 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
                     slot = base_slot + idx;
                     o = xyz(ray_o[slot]); d = xyz(ray_d[slot]); co = o; cd = d;
                     rb = make_raybox(o, d);
+                    if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
                     h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
                     stk[0] = SENTINEL; sp = 1; ref = sc.tlas_root;
                     have = true;
@@ -547,13 +535,9 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
         while (__popcll(__ballot(have && ref != SENTINEL)) > keep_going_above) {
             if (!have) continue;
             if (ref >= 0) {
-                const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
-                const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
                 if (COUNT) n_int++;
-                float tinL, tinR;
-                const bool hitL = box_hit(rb, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), h.t, tinL);
-                const bool hitR = box_hit(rb, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), h.t, tinR);
-                const int l = __float_as_int(q0.w), r = __float_as_int(q1.w);
+                bool hitL, hitR; float tinL, tinR; int l, r;
+                test_children<NODE32>(nodes, ref, rb, h.t, hitL, hitR, tinL, tinR, l, r);
                 if (hitL && hitR) {
                     const bool lfirst = tinL < tinR;
                     stk[sp * HPT_BLOCK] = lfirst ? r : l;
@@ -577,6 +561,7 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
                     }
                 } else if (ref == HPT_REF_RESTORE) {          // back from a mesh instance to the world-space ray
                     co = o; cd = d; rb = make_raybox(o, d);
+                    if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
                 } else {                                      // TLAS leaf: an instance
                     const uint32_t i = x - (uint32_t)HPT_INST_BASE;
                     const DInstance* in = sc.instances + i;
@@ -594,7 +579,8 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
                         const RayBox lrb = make_raybox(lo, ld);
                         float tin;
                         if (box_hit(lrb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
-                            co = lo; cd = ld; rb = lrb; cur_inst = i;
+                            co = lo; cd = ld; cur_inst = i;
+                            rb = NODE32 ? quant_slab(lrb, mesh->qbase, mesh->qscale) : lrb;
                             stk[sp * HPT_BLOCK] = HPT_REF_RESTORE;
                             sp++;
                             ref = mesh->root_ref;
@@ -615,7 +601,7 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
 
 // closest hit over a (sharded) queue through the TLAS: a workgroup takes groups of 4 chunks (1024 slots) so that lanes
 // that finish early find more rays to pull
-template <bool COUNT>
+template <bool COUNT, bool NODE32>
 __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
                                                        const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                        unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
@@ -627,7 +613,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
         const uint32_t first = g * GROUP;
         if (threadIdx.x == 0) *L.qhead = 0;
         __syncthreads();
-        if (first < cnt) drain_rays_tlas<COUNT>(sc, L, s * wv.cap + first, min(GROUP, cnt - first), ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
+        if (first < cnt) drain_rays_tlas<COUNT, NODE32>(sc, L, s * wv.cap + first, min(GROUP, cnt - first), ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
         __syncthreads();
     }
 }
@@ -639,13 +625,12 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_trace_rays
-template <bool COUNT>
+template <bool COUNT, bool NODE32>
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_trace_rays(const float4* __restrict__ nodes, const float4* __restrict__ tris, int n_nodes, int stack_entries, DMesh mesh, long long n,
              const float4* __restrict__ org, const float4* __restrict__ dir, float4* __restrict__ hit,
              uint8_t* __restrict__ side_out, unsigned long long* stat) {
     Lds L = lds_carve(stack_entries);
-    lds_load_nodes(L, nodes, n_nodes);
     int* stk = L.stack + threadIdx.x;
     unsigned n_int = 0, n_tri = 0;
     for (long long base = (long long)blockIdx.x * HPT_BLOCK; base < n; base += (long long)gridDim.x * HPT_BLOCK) {
@@ -656,7 +641,7 @@ k_trace_rays(const float4* __restrict__ nodes, const float4* __restrict__ tris, 
             const RayBox rb = make_raybox(o, d);
             float tin;
             if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin))
-                traverse_mesh<COUNT>(nodes, tris, L.ncache, L.n_cached, mesh.root_ref, o, d, HPT_INF, false, tm, prim, bu, bv, s, stk, n_int, n_tri);
+                traverse_mesh<COUNT, NODE32>(nodes, tris, mesh, o, d, HPT_INF, false, tm, prim, bu, bv, s, stk, n_int, n_tri);
             float4 h;
             if (prim >= 0) h = make_float4(tm, bu, bv, __int_as_float(prim - mesh.tri_base));
             else h = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
@@ -713,17 +698,16 @@ k_raygen(DScene sc, DPass ps) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_extend
-template <bool COUNT, bool TLAS>
+template <bool COUNT, bool TLAS, bool NODE32>
 __global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : HPT_EXTEND_WAVES, TLAS ? 4 : HPT_EXTEND_WAVES)))
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     Lds L = lds_carve(stack_entries);
     L.refill = refill;
-    lds_load_nodes(L, sc.nodes, sc.n_nodes);
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
-    if constexpr (TLAS) block_closest_hit_tlas<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
-    else block_closest_hit<COUNT>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    else block_closest_hit<COUNT, NODE32>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
                            c = wave_sum<unsigned long long>(n_inst);
@@ -873,12 +857,11 @@ __global__ void __launch_bounds__(HPT_BLOCK)
 k_scene_closest(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
                 float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, int stack_entries) {
     Lds L = lds_carve(stack_entries);
-    lds_load_nodes(L, sc.nodes, sc.n_nodes);
     unsigned c0 = 0, c1 = 0, c2 = 0;
     WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n;
     wv.cap = (uint32_t)((n + HPT_BLOCK - 1) / HPT_BLOCK) * HPT_BLOCK;
-    if (sc.use_tlas) block_closest_hit_tlas<false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2);
-    else block_closest_hit<false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2);
+    if (sc.use_tlas) { if (sc.node32) block_closest_hit_tlas<false, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit_tlas<false, false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
+    else { if (sc.node32) block_closest_hit<false, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit<false, false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
 }
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_scene_hitinfo(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
@@ -1136,15 +1119,15 @@ static inline int grid_for(uint64_t n, int max_blocks) {
 }
 // dynamic LDS of the traversal kernels: stack + node cache + work queue + queue counter (see lds_carve)
 static inline size_t trav_lds_bytes(int stack_entries, bool with_queue = true) {
-    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 4 * HPT_NODE_CACHE * sizeof(float4) + 16 + (with_queue ? HPT_QUEUE_CAP * sizeof(uint2) : 0);
+    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16 + (with_queue ? HPT_QUEUE_CAP * sizeof(uint2) : 0);
 }
 
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
                      const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat) {
     const int grid = grid_for((uint64_t)n, max_blocks);
     const size_t lds = trav_lds_bytes(mesh.stack_need);
-    if (count) hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, sc.n_nodes, mesh.stack_need, mesh, n, org, dir, hit, side, stat);
-    else hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, sc.n_nodes, mesh.stack_need, mesh, n, org, dir, hit, side, stat);
+    auto k = sc.node32 ? (count ? k_trace_rays<true, true> : k_trace_rays<false, true>) : (count ? k_trace_rays<true, false> : k_trace_rays<false, false>);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, sc.n_nodes, mesh.stack_need, mesh, n, org, dir, hit, side, stat);
 }
 void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
@@ -1162,7 +1145,8 @@ void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
     const size_t lds = trav_lds_bytes(stack_entries, !sc.use_tlas);
     // one kernel per (instrumented, two-level) combination: each path gets its own register allocation
-    auto k = sc.use_tlas ? (count ? k_extend<true, true> : k_extend<false, true>) : (count ? k_extend<true, false> : k_extend<false, false>);
+    auto k = sc.use_tlas ? (sc.node32 ? (count ? k_extend<true, true, true> : k_extend<false, true, true>) : (count ? k_extend<true, true, false> : k_extend<false, true, false>))
+                         : (sc.node32 ? (count ? k_extend<true, false, true> : k_extend<false, false, true>) : (count ? k_extend<true, false, false> : k_extend<false, false, false>));
     hipLaunchKernelGGL(k, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
 }
 void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {

@@ -61,7 +61,7 @@ class TraceStats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_instances", C.c_int32), ("n_mesh_instances", C.c_int32), ("n_meshes", C.c_int32), ("n_materials", C.c_int32),
                 ("n_nodes", C.c_int32), ("tlas_nodes", C.c_int32), ("uses_tlas", C.c_int32), ("stack_entries", C.c_int32),
-                ("n_triangles", C.c_int64), ("device_bytes", C.c_uint64)]
+                ("n_triangles", C.c_int64), ("device_bytes", C.c_uint64), ("node_bytes", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/hpt.h declares (tests check that the library exports all of them)

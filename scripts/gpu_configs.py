@@ -20,7 +20,7 @@ def run(ctx, name, desc, spp, depth, tree=None, S=0):
     st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_TIME_KERNELS)
     rays = st.rays_primary + st.rays_bounce; cr = cst.rays_primary + cst.rays_bounce
     info = sc.info()
-    bpr = (64.0 * cst.nodes_visited + 48.0 * cst.tris_tested + (128.0 * cst.inst_tests if info.uses_tlas else 0.0)) / cr + 52
+    bpr = (info.node_bytes * float(cst.nodes_visited) + 48.0 * cst.tris_tested + (128.0 * cst.inst_tests if info.uses_tlas else 0.0)) / cr + 52
     rec = {"config": name, "res": [desc.camera.width, desc.camera.height], "spp": spp, "depth": depth, "commit_s": round(t_commit, 3), "scene_MB": round(info.device_bytes / 1e6, 1), "tlas": int(info.uses_tlas),
            "seconds": round(st.seconds_total, 4), "Mrays_s": round(rays / st.seconds_total / 1e6, 1), "rays_per_sample": round(rays / (npix * spp), 3),
            "extend_s": round(st.seconds_extend, 4), "shade_s": round(st.seconds_shade, 4), "extend_Grays_s": round(rays / st.seconds_extend / 1e9, 3),

@@ -79,3 +79,35 @@ def test_tlas_equals_linear(ctx, olib, desc, monkeypatch):
     for k in ("node", "prim", "t", "side", "pos", "normal"):
         np.testing.assert_array_equal(a[k], b[k])
     lin.close(); tl.close()
+
+
+def test_node32_equals_node64(ctx, olib, desc, monkeypatch):
+    """16-bit quantised child boxes (Node32, default for trees that do not fit L2) against float boxes (Node64): boxes
+    only grow, so every hit record is identical -- mesh-local parity rays on the teapot (host tree), and a TLAS scene"""
+    import hpt
+    import rays as R
+    monkeypatch.setenv("HPT_NODE_FORMAT", "64")
+    a = hpt.Scene(ctx, desc, host_bvh=host_tree)
+    monkeypatch.setenv("HPT_NODE_FORMAT", "32")
+    b = hpt.Scene(ctx, desc, host_bvh=host_tree)
+    assert (a.info().node_bytes, b.info().node_bytes) == (64, 32)
+    assert b.info().device_bytes < a.info().device_bytes
+    osc = ol.OracleScene(olib, desc)
+    org, dirs = R.parity_rays(osc.meshes[0].box(), 1_000_000)
+    ga, gb = a.trace_rays(0, org, dirs), b.trace_rays(0, org, dirs)
+    for k in ("prim", "t", "u", "v", "side"):
+        np.testing.assert_array_equal(ga[k], gb[k])
+    # node visits grow by the outward rounding only: well under 1 %
+    assert ga["stats"].nodes_visited > 0 and gb["stats"].nodes_visited <= ga["stats"].nodes_visited * 1.01
+    ia, ib = a.render(spp=4, max_depth=6, seed=3), b.render(spp=4, max_depth=6, seed=3)
+    np.testing.assert_array_equal(ia["rgb"], ib["rgb"])
+    a.close(); b.close()
+    d = scenes.spheres(500)
+    monkeypatch.setenv("HPT_NODE_FORMAT", "64"); a = hpt.Scene(ctx, d)
+    monkeypatch.setenv("HPT_NODE_FORMAT", "32"); b = hpt.Scene(ctx, d)
+    assert a.info().uses_tlas and b.info().uses_tlas and b.info().node_bytes == 32
+    o, dd = camera_and_random_rays(ol.OracleScene(olib, d), d, 8000, 4)
+    ha, hb = a.intersect(o, dd), b.intersect(o, dd)
+    for k in ("node", "prim", "t", "side", "pos", "normal"):
+        np.testing.assert_array_equal(ha[k], hb[k])
+    a.close(); b.close()
