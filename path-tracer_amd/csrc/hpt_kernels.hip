@@ -5,7 +5,8 @@
 //   k_extend  : scene.rs:190-208,242-275, geometry.rs:30-97,132-221, bvh.rs:148-281  (closest hit)
 //   k_shade   : scene.rs:126-188,211-225,298-358,394-429 (+ stream compaction: ballot + wave prefix + 1 atomic/wave)
 //   k_resolve : main.rs:90-100,109-110 (per-pixel sum over samples in sample order, optional min/max)
-//   k_trace_rays / k_scene_intersect : parity / test entries (Mesh::intersect, Scene::intersect)
+//   k_trace_rays / k_scene_closest + k_scene_hitinfo : parity / test entries (Mesh::intersect, Scene::intersect)
+//   k_adaptive_select, k_divide : main.rs:101-110
 //
 // Numerics: compiled with -ffp-contract=off.  Everything that decides a hit (triangle, sphere, plane, the node
 // transform chain) keeps the reference's operation order with IEEE divide/sqrt, so t,u,v and hit ids are
@@ -25,7 +26,6 @@
 #ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 5
 #endif
-#define HPT_EXTEND_OCC __attribute__((amdgpu_waves_per_eu(HPT_EXTEND_WAVES, HPT_EXTEND_WAVES)))
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
 
