@@ -709,7 +709,7 @@ static int default_spp_per_pass(uint64_t npix, int want) {
 // kernel, 4 for the two-level one -- hpt_kernels.hip) and as fit into the CU's 160 KB of LDS.
 static int extend_grid(const hpt_scene* s) {
     const hpt_context* ctx = s->ctx;
-    int per_cu = ctx->extend_per_cu > 0 ? ctx->extend_per_cu : (s->ds.use_tlas ? 4 : 5);
+    int per_cu = ctx->extend_per_cu > 0 ? ctx->extend_per_cu : (s->ds.use_tlas ? 4 : 5) * 256 / HPT_BLOCK;
     const size_t lds = hptk_extend_lds_bytes(s->stack_entries, s->ds.use_tlas != 0);
     const int fit = (int)((160u * 1024u) / std::max<size_t>(lds, 1));
     per_cu = std::max(1, std::min(per_cu, fit));

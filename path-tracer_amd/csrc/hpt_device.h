@@ -18,7 +18,9 @@
 #pragma once
 #include <stdint.h>
 
-#define HPT_BLOCK 256          // threads per workgroup: 4 wave64
+#ifndef HPT_BLOCK
+#define HPT_BLOCK 256          // threads per workgroup: 4 wave64 (128 and 512 measured slower)
+#endif
 #define HPT_NODE_QUADS 4
 #define HPT_TRI_QUADS 3
 #define HPT_TRISHADE_QUADS 7
