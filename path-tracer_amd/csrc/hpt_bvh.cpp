@@ -1,7 +1,10 @@
 // hpt_bvh.cpp -- see hpt_bvh.h.  Host only; no recursion (reference trees can be O(n) deep).
 #include "hpt_bvh.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 #include <cstring>
 #include <limits>
 
@@ -63,8 +66,83 @@ void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, H
     tree_build_sah_boxes(b.data(), ntri, out);
 }
 
+// Binned SAH (16 bins; all three axes up to 4096 primitives, the longest axis above), one primitive per leaf.
+// A subtree over n primitives owns exactly 2n-1 consecutive node slots (its root first, then the left subtree, then
+// the right one), so subtrees are independent: the top of the tree is split on the calling thread until the ranges are
+// small, the ranges below are built by a pool of threads.  The result does not depend on the number of threads.
+namespace {
+struct SahBuilder {
+    static constexpr int NB = 16;
+    const std::vector<Box>& boxes; const std::vector<float>& cent; std::vector<int32_t>& ids; HostTree& out;
+    struct Job { int32_t node, lo, hi; };
+
+    // splits [lo, hi) (n >= 2) and returns the split position
+    int32_t split(int32_t lo, int32_t hi) const {
+        const int32_t n = hi - lo;
+        Box cb; cb.reset();
+        for (int32_t i = lo; i < hi; ++i) cb.grow(&cent[3 * (size_t)ids[i]]);
+        int axis = 0;
+        const float ext[3] = {cb.mx[0] - cb.mn[0], cb.mx[1] - cb.mn[1], cb.mx[2] - cb.mn[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        int32_t mid = lo + n / 2;
+        if (!(ext[axis] > 0.0f)) return mid;
+        int best_axis = -1, best_split = -1; float best_cost = std::numeric_limits<float>::infinity();
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!(ext[ax] > 0.0f)) continue;
+            if (n > 4096 && ax != axis) continue;   // large ranges: longest axis only
+            Box bb[NB]; int32_t cnt[NB];
+            for (int b = 0; b < NB; ++b) { bb[b].reset(); cnt[b] = 0; }
+            const float scale = (float)NB / ext[ax];
+            for (int32_t i = lo; i < hi; ++i) {
+                int b = (int)((cent[3 * (size_t)ids[i] + ax] - cb.mn[ax]) * scale);
+                b = std::min(std::max(b, 0), NB - 1);
+                bb[b].grow(boxes[ids[i]]); cnt[b]++;
+            }
+            float right_area[NB]; int32_t right_cnt[NB];
+            Box acc; acc.reset(); int32_t c = 0;
+            for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); c += cnt[b]; right_area[b] = c ? acc.half_area() : 0.0f; right_cnt[b] = c; }
+            acc.reset(); c = 0;
+            for (int b = 0; b < NB - 1; ++b) {
+                acc.grow(bb[b]); c += cnt[b];
+                if (c == 0 || right_cnt[b + 1] == 0) continue;
+                const float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
+            }
+        }
+        if (best_axis >= 0) {
+            const float scale = (float)NB / ext[best_axis];
+            const float mnv = cb.mn[best_axis];
+            auto it = std::partition(ids.begin() + lo, ids.begin() + hi, [&](int32_t id) {
+                int b = (int)((cent[3 * (size_t)id + best_axis] - mnv) * scale);
+                b = std::min(std::max(b, 0), NB - 1);
+                return b <= best_split;
+            });
+            const int32_t m = (int32_t)(it - ids.begin());
+            if (m > lo && m < hi) mid = m;
+        }
+        return mid;
+    }
+    // one step: leaf, or split + children in their fixed slots; pushes the child jobs
+    void step(const Job& j, std::vector<Job>& todo) const {
+        const int32_t n = j.hi - j.lo;
+        if (n == 1) { out.prim[j.node] = ids[j.lo]; return; }
+        const int32_t mid = split(j.lo, j.hi);
+        const int32_t l = j.node + 1, r = j.node + 2 * (mid - j.lo);   // the left subtree owns 2*(mid-lo)-1 slots
+        out.left[j.node] = l; out.right[j.node] = r;
+        todo.push_back({r, mid, j.hi});
+        todo.push_back({l, j.lo, mid});
+    }
+    void run(Job root) const { std::vector<Job> todo{root}; while (!todo.empty()) { const Job j = todo.back(); todo.pop_back(); step(j, todo); } }
+};
+int builder_threads() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) n = std::min(n > 0 ? n : v, v); }
+    return std::max(1, std::min(n, 16));
+}
+}  // namespace
+
 void tree_build_sah_boxes(const float* leaf_boxes, int32_t ntri, HostTree& out) {
-    const int NB = 16;
     std::vector<Box> boxes((size_t)ntri);
     std::vector<float> cent((size_t)ntri * 3);
     for (int32_t i = 0; i < ntri; ++i) {
@@ -73,65 +151,24 @@ void tree_build_sah_boxes(const float* leaf_boxes, int32_t ntri, HostTree& out) 
     }
     std::vector<int32_t> ids((size_t)ntri);
     for (int32_t i = 0; i < ntri; ++i) ids[i] = i;
-    out.left.clear(); out.right.clear(); out.prim.clear();
-    out.left.reserve(2 * (size_t)ntri); out.right.reserve(2 * (size_t)ntri); out.prim.reserve(2 * (size_t)ntri);
-    struct Job { int32_t node, lo, hi; };
-    std::vector<Job> jobs;
-    auto new_node = [&]() { out.left.push_back(-1); out.right.push_back(-1); out.prim.push_back(-1); return (int32_t)out.left.size() - 1; };
-    out.root = new_node();
-    jobs.push_back({out.root, 0, ntri});
-    while (!jobs.empty()) {
-        Job j = jobs.back(); jobs.pop_back();
-        const int32_t n = j.hi - j.lo;
-        if (n == 1) { out.prim[j.node] = ids[j.lo]; continue; }
-        Box cb; cb.reset();
-        for (int32_t i = j.lo; i < j.hi; ++i) cb.grow(&cent[3 * (size_t)ids[i]]);
-        int axis = 0;
-        float ext[3] = {cb.mx[0] - cb.mn[0], cb.mx[1] - cb.mn[1], cb.mx[2] - cb.mn[2]};
-        if (ext[1] > ext[axis]) axis = 1;
-        if (ext[2] > ext[axis]) axis = 2;
-        int32_t mid = j.lo + n / 2;
-        if (ext[axis] > 0.0f) {
-            int best_axis = -1, best_split = -1; float best_cost = std::numeric_limits<float>::infinity();
-            for (int ax = 0; ax < 3; ++ax) {
-                if (!(ext[ax] > 0.0f)) continue;
-                if (n > 4096 && ax != axis) continue;   // large ranges: longest axis only
-                Box bb[NB]; int32_t cnt[NB];
-                for (int b = 0; b < NB; ++b) { bb[b].reset(); cnt[b] = 0; }
-                const float scale = (float)NB / ext[ax];
-                for (int32_t i = j.lo; i < j.hi; ++i) {
-                    int b = (int)((cent[3 * (size_t)ids[i] + ax] - cb.mn[ax]) * scale);
-                    b = std::min(std::max(b, 0), NB - 1);
-                    bb[b].grow(boxes[ids[i]]); cnt[b]++;
-                }
-                float right_area[NB]; int32_t right_cnt[NB];
-                Box acc; acc.reset(); int32_t c = 0;
-                for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); c += cnt[b]; right_area[b] = c ? acc.half_area() : 0.0f; right_cnt[b] = c; }
-                acc.reset(); c = 0;
-                for (int b = 0; b < NB - 1; ++b) {
-                    acc.grow(bb[b]); c += cnt[b];
-                    if (c == 0 || right_cnt[b + 1] == 0) continue;
-                    float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
-                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
-                }
-            }
-            if (best_axis >= 0) {
-                const float scale = (float)NB / ext[best_axis];
-                const float mnv = cb.mn[best_axis];
-                auto it = std::partition(ids.begin() + j.lo, ids.begin() + j.hi, [&](int32_t id) {
-                    int b = (int)((cent[3 * (size_t)id + best_axis] - mnv) * scale);
-                    b = std::min(std::max(b, 0), NB - 1);
-                    return b <= best_split;
-                });
-                int32_t m = (int32_t)(it - ids.begin());
-                if (m > j.lo && m < j.hi) mid = m;
-            }
-        }
-        const int32_t l = new_node(), r = new_node();
-        out.left[j.node] = l; out.right[j.node] = r;
-        jobs.push_back({r, mid, j.hi});
-        jobs.push_back({l, j.lo, mid});
+    const size_t nn = 2 * (size_t)ntri - 1;
+    out.left.assign(nn, -1); out.right.assign(nn, -1); out.prim.assign(nn, -1);
+    out.root = 0;
+    const SahBuilder B{boxes, cent, ids, out};
+    const int nthreads = ntri >= (1 << 16) ? builder_threads() : 1;
+    if (nthreads == 1) { B.run({0, 0, ntri}); return; }
+    // top of the tree on this thread, down to ranges of about ntri / (8 * threads) primitives
+    const int32_t grain = std::max(4096, ntri / (8 * nthreads));
+    std::vector<SahBuilder::Job> todo{{0, 0, ntri}}, tasks;
+    while (!todo.empty()) {
+        const SahBuilder::Job j = todo.back(); todo.pop_back();
+        if (j.hi - j.lo <= grain) tasks.push_back(j); else B.step(j, todo);
     }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t)
+        pool.emplace_back([&]() { for (size_t k; (k = next.fetch_add(1)) < tasks.size();) B.run(tasks[k]); });
+    for (std::thread& th : pool) th.join();
 }
 
 bool flatten_tree(const HostTree& tree, const float* leaf_boxes, int32_t nleaf, FlatMesh& out, std::string& err) {

@@ -11,7 +11,7 @@ from conftest import ROOT
 def test_bvh_validation_under_sanitizers(tmp_path):
     src = os.path.join(ROOT, "path-tracer_amd", "csrc")
     exe = str(tmp_path / "bvh_fuzz")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", src, "-o", exe,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread", "-I", src, "-o", exe,
                            os.path.join(ROOT, "tests", "native", "bvh_fuzz.cpp"), os.path.join(src, "hpt_bvh.cpp")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
