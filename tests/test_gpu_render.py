@@ -259,3 +259,23 @@ def test_full_size_properties(ctx, desc):
     sc.render_round_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=3, first_sample=2, max_depth=8, seed=2)
     assert torch.equal(a, c)
     sc.close(); sc2.close()
+
+
+def test_independent_rng_image_parity(ctx, olib, desc):
+    """SURVEY 8d.7, independent-RNG mode -- the stand-in for the reference's OS-seeded rand: the GPU image with ITS OWN
+    seed must be as close to a CPU render as two CPU renders with different seeds are to each other:
+    RMSE(GPU, CPU_A) <= 1.25 x RMSE(CPU_A, CPU_B), and the per-channel mean signed error <= 0.5 % of the mean."""
+    import hpt
+    d = resized(desc, 128, 96)
+    osc = ol.OracleScene(olib, d)
+    cpu_a = osc.render(spp=128, max_depth=8, seed=101)["rgb"]
+    cpu_b = osc.render(spp=128, max_depth=8, seed=202)["rgb"]
+    sc = hpt.Scene(ctx, d, host_bvh=host_tree)
+    gpu = sc.render(spp=128, max_depth=8, seed=303)["rgb"]
+    sc.close()
+    rmse = lambda x, y: float(np.sqrt(((x - y) ** 2).mean()))
+    noise = rmse(cpu_a, cpu_b)
+    assert noise > 0 and rmse(gpu, cpu_a) <= 1.25 * noise and rmse(gpu, cpu_b) <= 1.25 * noise
+    ref_mean = 0.5 * (cpu_a + cpu_b).reshape(-1, 3).mean(axis=0)
+    signed = gpu.reshape(-1, 3).mean(axis=0) - ref_mean
+    assert (np.abs(signed) <= 0.005 * ref_mean).all(), (signed, ref_mean)
