@@ -143,11 +143,17 @@ def main():
         accum = torch.zeros(npix * 3, device="cuda", dtype=torch.float32)
         image = torch.zeros(npix * 3, device="cuda", dtype=torch.float32)
 
+        reduce_events = []   # the one exchange step, also shown on its own (it is inside the timed region)
+
         def step():
             st = scene.render_device(accum.data_ptr(), want_stats=True, spp=count, first_sample=first, max_depth=args.depth,
                                      seed=1, spp_per_pass=args.spp_per_pass, flags=flags)
             if world > 1 and backend == "nccl":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
                 dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)     # RCCL sum-reduce of the float accumulators over xGMI
+                e1.record(stream)
+                reduce_events.append((e0, e1))
             elif world > 1:                                         # rehearsal only: reduce through host memory
                 stream.synchronize()
                 host = accum.cpu()
@@ -159,6 +165,7 @@ def main():
 
         for _ in range(args.warmup):
             step()
+        reduce_events.clear()
         stream.synchronize()
         if world > 1:
             dist.barrier()
@@ -209,6 +216,7 @@ def main():
             "samples_per_px_per_s": round(args.spp * args.steps / elapsed, 3),
             "image_mean": [round(float(v), 6) for v in image.view(-1, 3).mean(dim=0).cpu()],
             "rays_per_step": rays_total / args.steps,
+            "reduce_ms_per_step": round(sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1), 4) if reduce_events else 0.0,
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None, "algorithmic_bytes_per_launch": int(bytes_per_ray * rays_local / max(ext_launches, 1)),
