@@ -148,17 +148,18 @@ def main():
         def step():
             st = scene.render_device(accum.data_ptr(), want_stats=True, spp=count, first_sample=first, max_depth=args.depth,
                                      seed=1, spp_per_pass=args.spp_per_pass, flags=flags)
-            if world > 1 and backend == "nccl":
+            if world > 1:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)     # RCCL sum-reduce of the float accumulators over xGMI
+                if backend == "nccl":
+                    dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)     # RCCL sum-reduce of the float accumulators over xGMI
+                else:                                                   # rehearsal only: reduce through host memory
+                    stream.synchronize()
+                    host = accum.cpu()
+                    dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                    accum.copy_(host)
                 e1.record(stream)
                 reduce_events.append((e0, e1))
-            elif world > 1:                                         # rehearsal only: reduce through host memory
-                stream.synchronize()
-                host = accum.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                accum.copy_(host)
             if rank == 0:
                 torch.div(accum, float(args.spp), out=image)        # main.rs:110
             return st
