@@ -158,39 +158,53 @@ __device__ __forceinline__ bool intersect_plane(f3 pos, f3 dir, float& t, int& s
 // Slab form of a ray for box tests: the ray parameter where it crosses the plane {axis = c} is t(c) = c * a + b.
 // For float coordinates a = 1/d, b = -o/d; for Node32's 16-bit coordinates (c = qbase + q * qscale) the grid folds
 // into the coefficients: t(q) = q * (qscale * a) + (qbase * a + b), so a quantised box costs the same 12 fma.
-struct Slab { float ax, ay, az, bx, by, bz; };
+//
+// The test must never cull a box the exact arithmetic enters (hits are decided by the exact primitive tests, boxes
+// only prune).  Two roundings matter: a = fl(1/d) scales every t by (1 +- 2^-24) -- covered by the relative 1e-6 on
+// t_out and on the bound -- and b = fl(o * a) is off by half an ulp of |b|, an ABSOLUTE error in t that no relative
+// slack covers when the ray starts far from the origin of the space but close to the box (|b| >> |t|).  So each axis
+// keeps TWO offsets, blo = b - e and bhi = b + e with e = 2^-22 |b| (Node32: plus the rounding of the folded grid
+// offset): the entry plane is evaluated with blo, the exit plane with bhi.  Which coordinate of a box is the entry
+// one follows from the sign of a (pos*), so the per-axis min/max of the usual slab test become selects: same count.
+struct Slab { float ax, ay, az, blx, bly, blz, bhx, bhy, bhz; };
 typedef Slab RayBox;
 __device__ __forceinline__ float safe_dir(float v) { return fabsf(v) < 1.0e-30f ? copysignf(1.0e-30f, v) : v; }
+#define HPT_SLAB_EPS 2.4e-7f   // 2^-22
 __device__ __forceinline__ Slab make_raybox(f3 o, f3 d) {
     Slab r;
     r.ax = 1.0f / safe_dir(d.x); r.ay = 1.0f / safe_dir(d.y); r.az = 1.0f / safe_dir(d.z);
-    r.bx = -(o.x * r.ax); r.by = -(o.y * r.ay); r.bz = -(o.z * r.az);
+    const float bx = -(o.x * r.ax), by = -(o.y * r.ay), bz = -(o.z * r.az);
+    const float ex = HPT_SLAB_EPS * fabsf(bx), ey = HPT_SLAB_EPS * fabsf(by), ez = HPT_SLAB_EPS * fabsf(bz);
+    r.blx = bx - ex; r.bly = by - ey; r.blz = bz - ez;
+    r.bhx = bx + ex; r.bhy = by + ey; r.bhz = bz + ez;
     return r;
 }
 __device__ __forceinline__ Slab quant_slab(const Slab& s, const float* qbase, const float* qscale) {
     Slab q;
     q.ax = qscale[0] * s.ax; q.ay = qscale[1] * s.ay; q.az = qscale[2] * s.az;
-    q.bx = __builtin_fmaf(qbase[0], s.ax, s.bx); q.by = __builtin_fmaf(qbase[1], s.ay, s.by); q.bz = __builtin_fmaf(qbase[2], s.az, s.bz);
+    // folded offsets qbase * a + b, pushed outward by the rounding of this fma (relative to the larger operand)
+    const float mx = HPT_SLAB_EPS * fmaxf(fabsf(qbase[0] * s.ax), fabsf(s.blx)), my = HPT_SLAB_EPS * fmaxf(fabsf(qbase[1] * s.ay), fabsf(s.bly)),
+                mz = HPT_SLAB_EPS * fmaxf(fabsf(qbase[2] * s.az), fabsf(s.blz));
+    q.blx = __builtin_fmaf(qbase[0], s.ax, s.blx) - mx; q.bly = __builtin_fmaf(qbase[1], s.ay, s.bly) - my; q.blz = __builtin_fmaf(qbase[2], s.az, s.blz) - mz;
+    q.bhx = __builtin_fmaf(qbase[0], s.ax, s.bhx) + mx; q.bhy = __builtin_fmaf(qbase[1], s.ay, s.bhy) + my; q.bhz = __builtin_fmaf(qbase[2], s.az, s.bhz) + mz;
     return q;
 }
-// slab test (bvh.rs:225-281 semantics + the two culls the reference lacks: box behind the origin, box beyond bound).
-// It never decides a hit: boxes are supersets of their triangles and the relative slack (1e-6 on tout and on the
-// bound) keeps the fma/reciprocal form from culling a box the reference's divide form (bvh.rs:233-234) enters.
-__device__ __forceinline__ bool slab_hit(float t0x, float t1x, float t0y, float t1y, float t0z, float t1z, float bound, float& tin) {
-    tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-    const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * 1.000001f;
+// slab test (bvh.rs:225-281 semantics + the two culls the reference lacks: box behind the origin, box beyond bound):
+// lo* / hi* = the smaller / larger coordinate of the box per axis (float, or the 16-bit grid value as float)
+__device__ __forceinline__ bool slab_hit(const Slab& s, float lox, float hix, float loy, float hiy, float loz, float hiz, float bound, float& tin) {
+    const bool px = s.ax > 0.0f, py = s.ay > 0.0f, pz = s.az > 0.0f;   // (quantised slabs keep the sign: qscale > 0)
+    const float ex = __builtin_fmaf(px ? lox : hix, s.ax, s.blx), ey = __builtin_fmaf(py ? loy : hiy, s.ay, s.bly), ez = __builtin_fmaf(pz ? loz : hiz, s.az, s.blz);
+    const float xx = __builtin_fmaf(px ? hix : lox, s.ax, s.bhx), xy = __builtin_fmaf(py ? hiy : loy, s.ay, s.bhy), xz = __builtin_fmaf(pz ? hiz : loz, s.az, s.bhz);
+    tin = fmaxf(fmaxf(ex, ey), ez);
+    const float tout = fminf(fminf(xx, xy), xz) * 1.000001f;
     return (tin <= tout) && (tout >= 0.0f) && (tin <= bound * 1.000001f);
 }
 __device__ __forceinline__ bool box_hit(const Slab& rb, float3 bmin, float3 bmax, float bound, float& tin) {
-    return slab_hit(__builtin_fmaf(bmin.x, rb.ax, rb.bx), __builtin_fmaf(bmax.x, rb.ax, rb.bx),
-                    __builtin_fmaf(bmin.y, rb.ay, rb.by), __builtin_fmaf(bmax.y, rb.ay, rb.by),
-                    __builtin_fmaf(bmin.z, rb.az, rb.bz), __builtin_fmaf(bmax.z, rb.az, rb.bz), bound, tin);
+    return slab_hit(rb, bmin.x, bmax.x, bmin.y, bmax.y, bmin.z, bmax.z, bound, tin);
 }
 // 16-bit box word = min | max << 16 along one axis
 __device__ __forceinline__ bool qbox_hit(const Slab& qs, uint32_t wx, uint32_t wy, uint32_t wz, float bound, float& tin) {
-    return slab_hit(__builtin_fmaf((float)(wx & 0xffffu), qs.ax, qs.bx), __builtin_fmaf((float)(wx >> 16), qs.ax, qs.bx),
-                    __builtin_fmaf((float)(wy & 0xffffu), qs.ay, qs.by), __builtin_fmaf((float)(wy >> 16), qs.ay, qs.by),
-                    __builtin_fmaf((float)(wz & 0xffffu), qs.az, qs.bz), __builtin_fmaf((float)(wz >> 16), qs.az, qs.bz), bound, tin);
+    return slab_hit(qs, (float)(wx & 0xffffu), (float)(wx >> 16), (float)(wy & 0xffffu), (float)(wy >> 16), (float)(wz & 0xffffu), (float)(wz >> 16), bound, tin);
 }
 // One interior node: fetch the record (Node64: 4 quads, Node32: 2) and test both child boxes against the lane's slab
 // (`ns` must be the quantised slab of the tree's grid for Node32).
@@ -505,7 +519,7 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
     uint32_t slot = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), co = o, cd = d;
     Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
-    RayBox rb = make_raybox(o, d);
+    RayBox rb = make_raybox(co, cd);
     int ref = SENTINEL, sp = 1; uint32_t cur_inst = 0;
     for (;;) {
         if (have && ref == SENTINEL) {   // ray finished
