@@ -67,6 +67,32 @@ def test_library_built_tree_gives_same_hits(ctx, desc, oscene):
     sc.close()
 
 
+def test_far_from_the_origin(ctx, olib, desc, monkeypatch):
+    """Box culling stays conservative when |origin| >> |t|: the teapot moved far away, rays starting next to it --
+    b = fl(o/d) then carries an absolute error far above any relative slack on t (the kernels before the per-axis bound
+    lost 7 of 400 k hits here).  Host tree and library tree; Node32 at the distance where its grid still resolves
+    (at 5e4 one quantum is below the vertex ulp and commit keeps Node64)."""
+    import copy
+    import hpt
+    import oracle_lib as ol
+    for offset, formats in (((3.0e4, -2.0e4, 5.0e4), ("64",)), ((600.0, -400.0, 500.0), ("64", "32"))):
+        m = copy.deepcopy(desc.meshes[0])
+        m.verts = (m.verts + np.array(offset, np.float32)).astype(np.float32)
+        om = ol.OracleMesh(olib, m)
+        org, dirs = R.parity_rays(om.box(), 400_000, seed=21)
+        o = om.intersect(org, dirs)
+        assert (o["prim"] >= 0).mean() > 0.2
+        for fmt in formats:
+            monkeypatch.setenv("HPT_NODE_FORMAT", fmt)
+            for tree in (host_tree(m), None):
+                sc = hpt.Scene(ctx)
+                mid = sc.add_mesh(m, tree)
+                sc.commit()
+                assert sc.info().node_bytes == int(fmt)
+                compare(sc.trace_rays(mid, org, dirs), o)
+                sc.close()
+
+
 def test_edge_cases(ctx, olib):
     import hpt
     import oracle_lib as ol
