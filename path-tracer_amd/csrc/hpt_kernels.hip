@@ -21,7 +21,7 @@
 #define PI_F 3.14159265358979323846f
 // register budgets (waves per SIMD the allocator must reach) of the two hot kernels; see DESIGN.md tuning log
 #ifndef HPT_EXTEND_WAVES
-#define HPT_EXTEND_WAVES 5       // linear-instance-list kernel: 90 VGPRs; the two-level kernel (116 VGPRs) stays at 4
+#define HPT_EXTEND_WAVES 4       // linear-instance-list kernel: 90 VGPRs; the two-level kernel (116 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 5
@@ -281,15 +281,25 @@ struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 //  wait per step costs more than the fetches it saves)
 struct Lds {
     int* stack; uint2* queue; unsigned* qn; unsigned* qhead; int refill;
+    // deferred triangle tests of drain_queue (only carved when the queue is): per lane the best (t, triangle) key of the
+    // mesh it is walking + u, v, side of that hit; per wave a list of (triangle, owner lane) pairs waiting to be tested
+    unsigned long long* best; float* du; float* dv; uint32_t* dsf; uint32_t* ltri; uint8_t* lown;
 };
+#define HPT_LEAF_CAP 192      // >= 63 left over + 2 appended per lane in one step
 __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L;
     L.stack = (int*)lds_raw;
     L.qn = (unsigned*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
     L.qhead = L.qn + 1;
-    L.queue = (uint2*)(L.qn + 4);      // the two-level (TLAS) path launches without the queue
-    L.refill = 16;
+    L.queue = (uint2*)(L.qn + 4);      // the two-level (TLAS) path launches without the queue and what follows it
+    L.best = (unsigned long long*)(L.queue + HPT_QUEUE_CAP);
+    L.du = (float*)(L.best + HPT_BLOCK);
+    L.dv = L.du + HPT_BLOCK;
+    L.dsf = (uint32_t*)(L.dv + HPT_BLOCK);
+    L.ltri = L.dsf + HPT_BLOCK;
+    L.lown = (uint8_t*)(L.ltri + (HPT_BLOCK / 64) * HPT_LEAF_CAP);
+    L.refill = 24;
     return L;
 }
 // Sharded wavefront queues.  A queue of capacity shards*cap slots is split into `shards` segments; segment s holds
@@ -340,53 +350,159 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
     return false;
 }
 
-// Phase 2 of block_closest_hit: drain the LDS queue (cnt items) with persistent lanes.  A lane owns one queued ray at a
-// time: it walks the BVHs of the mesh instances that ray still has to visit (trace order = visiting order) and writes
-// the final hit record.  The inner loop is nothing but traversal steps; the wave leaves it as soon as L.refill lanes
-// have finished their mesh, merges their results and hands them the next queued ray (node visits per ray are
-// heavy-tailed, 20..300: without the refill a wave runs as long as its slowest ray with most lanes idle).
+// Deferred triangle tests of one wave: entries [first, first + n) of its pending list, one per lane (n <= 64, uniform).
+// The tester lane fetches the owner lane's mesh-local ray through the LDS crossbar, runs the exact triangle test and
+// merges a hit into the owner's key with a 64-bit LDS min: key = t bits << 32 | triangle, so the minimum is the nearest
+// hit and, on equal t, the lower triangle index (the order-independent tie rule of traverse_mesh).  The lane whose key
+// is the minimum afterwards leaves u, v and the side beside it (LDS operations of one wave execute in order).
+#define HPT_KEY_NONE 0x7f800000ffffffffull      // t = +inf, no triangle
+template <bool COUNT>
+__device__ __forceinline__ void test_pending(const Lds& L, const float4* __restrict__ tris, unsigned first, unsigned n,
+                                             f3 lo, f3 ld, unsigned& n_tri) {
+    const unsigned lane = threadIdx.x & 63u, wbase = threadIdx.x & ~63u, wave = threadIdx.x >> 6;
+    const bool act = lane < n;
+    const unsigned e = wave * HPT_LEAF_CAP + first + (act ? lane : 0u);
+    const uint32_t tri = L.ltri[e];
+    const int owner = (int)L.lown[e];
+    f3 po, pd;
+    po.x = __shfl(lo.x, owner); po.y = __shfl(lo.y, owner); po.z = __shfl(lo.z, owner);
+    pd.x = __shfl(ld.x, owner); pd.y = __shfl(ld.y, owner); pd.z = __shfl(ld.z, owner);
+    if (act) {
+        const float4* tq = tris + tri * (uint32_t)HPT_TRI_QUADS;
+        const float4 a = tq[0], ab = tq[1], ac = tq[2];
+        if (COUNT) n_tri++;
+        float t, u, v; int s;
+        if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), po, pd, t, u, v, s)) {
+            uint32_t tb = __float_as_uint(t);
+            const bool negzero = tb == 0x80000000u;      // t = -0 passes "t < 0 -> miss": ordered as +0, sign kept aside
+            if (negzero) tb = 0u;
+            const unsigned long long key = ((unsigned long long)tb << 32) | tri;
+            unsigned long long* slot = L.best + wbase + owner;
+            atomicMin(slot, key);
+            __builtin_amdgcn_wave_barrier();
+            if (*(volatile unsigned long long*)slot == key) {
+                L.du[wbase + owner] = u; L.dv[wbase + owner] = v; L.dsf[wbase + owner] = (uint32_t)s | (negzero ? 2u : 0u);
+            }
+        }
+    }
+}
+
+// Closest hit over the rays of a (sharded) queue (scene.rs:190-208).  Every WAVE is a persistent worker of its own (no
+// workgroup barrier anywhere): it takes 64-ray pieces of the input (piece x = quarter x % 4 of chunk x / 4, pieces
+// x = global wave, + number of waves, ...) and alternates between two kinds of work.
+//  phase 1 (all 64 lanes, uniform control flow): every analytic instance (sphere / plane) in visiting order, plus the
+//          root-box test of the first mesh instance the ray enters; such a ray is appended to the wave's LDS queue
+//          (ring of HPT_QUEUE_CAP / 4 items) instead of being traversed; runs whenever fewer than 64 rays are queued
+//  phase 2 (persistent lanes): a lane owns one queued ray at a time: it walks the BVHs of the mesh instances that ray
+//          still has to visit (trace order = visiting order) and writes the final hit record.  The inner loop is
+//          nothing but box steps: a child that is a leaf and whose box the ray enters is not walked into but appended
+//          to the wave's pending list (triangle, owner lane), and as soon as 64 are pending the whole wave tests them,
+//          one pair per lane (test_pending) -- one-triangle leaves reach a wave at ~4 per step, so testing them in
+//          place ran the 90-instruction triangle block at 7 % lane utilisation in every step.  The owner's culling
+//          bound is refreshed from its key after each batch (a stale bound only costs visits, never a hit).  The wave
+//          leaves the inner loop as soon as L.refill lanes have finished their mesh, tests what is still pending,
+//          merges the results and hands the idle lanes the next queued rays.
+// Rays in flight stay in their lanes across phase 1, so the only under-filled steps of a wave are the ones at the very
+// end of the launch (node visits per ray are heavy-tailed, 20..300: when the queue was drained to the last ray before
+// each refill -- the first version -- every drain ended in such a tail and half of all lane-steps were idle).
+// Rays are identified by their slot i; results go to hit[i] / hit_inst[i] exactly once per ray.
 template <bool COUNT, bool NODE32>
-__device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsigned cnt, const float4* __restrict__ ray_o,
-                                            const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
-                                            unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+__device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
+                                                  const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
+                                                  unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    constexpr unsigned WAVES = HPT_BLOCK / 64, QW = HPT_QUEUE_CAP / WAVES;
+    static_assert((QW & (QW - 1)) == 0 && QW >= 128, "per-wave ring: power of two, room for 63 + 64 items");
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
     int* stk = L.stack + threadIdx.x;
+    uint2* queue = L.queue + wave * QW;
+    unsigned long long* mybest = L.best + threadIdx.x;
+    const unsigned lbase = wave * HPT_LEAF_CAP;
     const int SENTINEL = (int)0x80000000;
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
-    bool have = false, exhausted = false;
+    // input pieces: none beyond the fullest segment
+    uint32_t maxcnt = wv.n_linear;
+    if (wv.counts) {
+        maxcnt = lane < wv.shards ? wv.counts[lane * HPT_COUNT_STRIDE] : 0u;
+        for (unsigned k = lane + 64u; k < wv.shards; k += 64u) maxcnt = max(maxcnt, wv.counts[k * HPT_COUNT_STRIDE]);
+        for (int off = 32; off > 0; off >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor((int)maxcnt, off));
+    }
+    maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+    const uint32_t total = wv.shards * ((maxcnt + HPT_BLOCK - 1) / HPT_BLOCK) * WAVES;
+    const uint32_t xstep = gridDim.x * WAVES;
+    uint32_t x = blockIdx.x * WAVES + wave;
+    unsigned qn = 0, qhead = 0, pend = 0;                // wave-uniform: ring counters (monotonic), pending-list fill
+    bool have = false;
     uint32_t slot = 0; int mpos = 0, first_mpos = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), lo = o, ld = d;
+    f3 lo = mk3(0, 0, 0), ld = mk3(0, 0, 1);
     Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
-    RayBox rb = make_raybox(o, d);
-    float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, side = 0, ref = SENTINEL, sp = 1, inst_idx = 0; bool tie_ok = false;
+    RayBox rb = make_raybox(lo, ld);
+    float tm = HPT_INF; int ref = SENTINEL, sp = 1, inst_idx = 0;
     for (;;) {
-        // ---- lanes without a ray pull the next queued one
+        // ---- phase 1 until a full wave of rays is queued (or the input ends)
+        while (x < total && qn - qhead < 64u) {
+            const uint32_t w = x / WAVES, sub = x % WAVES;
+            x += xstep;
+            const uint32_t seg = w % wv.shards, k = w / wv.shards;
+            const uint32_t cnt = wv.counts ? wv.counts[seg * HPT_COUNT_STRIDE] : wv.n_linear;
+            const uint32_t off0 = k * HPT_BLOCK + sub * 64u;
+            if (off0 >= cnt) continue;
+            const uint32_t i = seg * wv.cap + off0 + lane;
+            bool queued = false;
+            uint2 item = make_uint2(0, 0);
+            if (off0 + lane < cnt) {
+                Hit a;
+                queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, a, item, n_inst);
+                hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
+            }
+            const unsigned long long mask = __ballot(queued);
+            if (queued) queue[(qn + (unsigned)__popcll(mask & below)) & (QW - 1u)] = item;
+            qn += (unsigned)__popcll(mask);
+            // the interim records are read back by whichever lane of this wave pulls the ray
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
+        // ---- lanes without a ray pull the next queued ones
         bool need_setup = false;
-        if (!exhausted) {
-            bool tried = false;
-            if (!have) {
-                tried = true;
-                const unsigned idx = atomicAdd(L.qhead, 1u);
-                if (idx < cnt) {
-                    const uint2 it = L.queue[idx];
+        {
+            const unsigned long long idle = __ballot(!have);
+            const unsigned avail = qn - qhead;
+            if (idle != 0ull && avail != 0u) {
+                const unsigned rank = (unsigned)__popcll(idle & below);
+                if (!have && rank < avail) {
+                    const uint2 it = queue[(qhead + rank) & (QW - 1u)];
                     slot = it.x; mpos = first_mpos = (int)it.y;
-                    // 8-byte items keep the queue at 8 KB of LDS (5 workgroups per CU fit); the best analytic hit of
-                    // phase 1 comes back from hit[] / hit_inst[] with the ray itself (same round trip, L2-resident)
+                    // 8-byte items keep the queues at 8 KB of LDS; the best analytic hit of phase 1 comes back from
+                    // hit[] / hit_inst[] (L2-resident)
                     h.t = hit[slot].x; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = hit_inst[slot];
-                    o = xyz(ray_o[slot]); d = xyz(ray_d[slot]);
                     have = true; need_setup = true;
                 }
+                const unsigned nidle = (unsigned)__popcll(idle);
+                qhead += nidle < avail ? nidle : avail;
             }
-            exhausted = __ballot(tried && !have) != 0ull;
         }
-        // ---- lanes whose mesh is finished merge its result and move on to the ray's next mesh instance
+        const bool exhausted = x >= total && qn == qhead;      // nothing left to pull, ever
+        // ---- lanes whose mesh is finished (nothing of theirs is pending: the list was emptied below) merge its result
+        //      and move on to the ray's next mesh instance
         if (have && !need_setup && ref == SENTINEL) {
-            if (prim >= 0) { h.t = tm; h.u = bu; h.v = bv; h.prim = prim; h.inst_side = (uint32_t)inst_idx | ((uint32_t)side << 31); }
+            const unsigned long long key = *mybest;
+            if ((uint32_t)key != 0xffffffffu) {
+                const float t = __uint_as_float((uint32_t)(key >> 32));
+                // replaces the scene-level nearest iff t < h.t, or t == h.t and this instance comes EARLIER in the
+                // reference's visiting order than the holder of h.t (scene.rs:196,251 keep the earlier node on equal t)
+                const bool tie_ok = (uint32_t)inst_idx < (h.inst_side & 0x7fffffffu);
+                if (t < h.t || (tie_ok && t == h.t)) {
+                    const uint32_t sf = L.dsf[threadIdx.x];
+                    h.t = (sf & 2u) ? -0.0f : t; h.u = L.du[threadIdx.x]; h.v = L.dv[threadIdx.x]; h.prim = (int)(uint32_t)key;
+                    h.inst_side = (uint32_t)inst_idx | ((sf & 1u) << 31);
+                }
+            }
             ++mpos;
             need_setup = true;
         }
         // ---- setup: next mesh instance whose root box the ray enters, or retire the ray
         if (need_setup) {
+            const f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
             for (;;) {
                 if (mpos >= sc.n_mesh_instances) {
                     hit[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
@@ -409,8 +525,7 @@ __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsi
                 float tin;
                 if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
                     if (NODE32) rb = quant_slab(rb, mesh->qbase, mesh->qscale);   // from here on rb addresses the tree's 16-bit grid
-                    tm = HPT_INF; prim = -1; bu = 0.0f; bv = 0.0f; side = 0;
-                    tie_ok = (uint32_t)inst_idx < (h.inst_side & 0x7fffffffu);
+                    tm = HPT_INF; *mybest = HPT_KEY_NONE;
                     stk[0] = SENTINEL; sp = 1; ref = mesh->root_ref;
                     break;
                 }
@@ -418,83 +533,51 @@ __device__ __forceinline__ void drain_queue(const DScene& sc, const Lds& L, unsi
             }
         }
         if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
-        // ---- traversal steps until enough lanes are done (all of them once the queue is empty)
+        // ---- box steps until enough lanes are done (all of them once nothing is left to pull)
         const int keep_going_above = exhausted ? 0 : 64 - L.refill;
         while (__popcll(__ballot(ref != SENTINEL)) > keep_going_above) {
-            // (gating the triangle block on ">= K lanes wait at a leaf" measured +-1 % for K = 2..8 and slower above:
-            // what it saves in instructions it loses in idle lanes)
+            bool leafL = false, leafR = false; int l = 0, r = 0;
+#ifdef HPT_DEBUG_SLOTS      // tuning builds: lane slots of the inner loop are added to the instance-test counter
+            if (COUNT && (HPT_DEBUG_SLOTS == 1 || (HPT_DEBUG_SLOTS == 2 && exhausted) || (HPT_DEBUG_SLOTS == 3 && !have))) n_inst++;
+#endif
             if (ref >= 0) {
                 if (COUNT) n_int++;
-                bool hitL, hitR; float tinL, tinR; int l, r;
+                bool hitL, hitR; float tinL, tinR;
                 test_children<NODE32>(nodes, ref, rb, fminf(tm, h.t), hitL, hitR, tinL, tinR, l, r);
-                if (hitL && hitR) {
+                leafL = hitL && l < 0; leafR = hitR && r < 0;
+                const bool intL = hitL && l >= 0, intR = hitR && r >= 0;
+                if (intL && intR) {
                     const bool lfirst = tinL < tinR;
                     stk[sp * HPT_BLOCK] = lfirst ? r : l;
                     sp++;
                     ref = lfirst ? l : r;
-                } else if (hitL) ref = l;
-                else if (hitR) ref = r;
+                } else if (intL) ref = l;
+                else if (intR) ref = r;
                 else { --sp; ref = stk[sp * HPT_BLOCK]; }
-            } else if (ref != SENTINEL) {
-                const int tri = ~ref;
-                const float4* tq = tris + (uint32_t)tri * (uint32_t)HPT_TRI_QUADS;
-                const float4 a = tq[0], ab = tq[1], ac = tq[2];
-                if (COUNT) n_tri++;
-                float t, u, v; int s;
-                if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), lo, ld, t, u, v, s)) {
-                    // equal t inside a mesh: the lower triangle index wins (order-independent => deterministic; the
-                    // reference's "later visited wins" depends on its own tree, north_star excludes edge rays)
-                    if ((t < tm || (t == tm && tri < prim)) && (t < h.t || (tie_ok && t == h.t))) { tm = t; prim = tri; bu = u; bv = v; side = s; }
+            } else if (ref != SENTINEL) {      // a mesh whose root is a leaf
+                leafL = true; l = ref;
+                --sp; ref = stk[sp * HPT_BLOCK];
+            }
+            const unsigned long long mL = __ballot(leafL), mR = __ballot(leafR);
+            if (mL | mR) {
+                if (leafL) { const unsigned e = lbase + pend + (unsigned)__popcll(mL & below); L.ltri[e] = (uint32_t)~l; L.lown[e] = (uint8_t)lane; }
+                pend += (unsigned)__popcll(mL);
+                if (leafR) { const unsigned e = lbase + pend + (unsigned)__popcll(mR & below); L.ltri[e] = (uint32_t)~r; L.lown[e] = (uint8_t)lane; }
+                pend += (unsigned)__popcll(mR);
+                if (pend >= 64u) {
+                    do { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); } while (pend >= 64u);
+                    tm = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
                 }
-                --sp;
-                ref = stk[sp * HPT_BLOCK];
             }
         }
+        // ---- what is still pending is tested before any lane merges or changes its ray
+        while (pend) {
+            const unsigned n = pend < 64u ? pend : 64u;
+            pend -= n;
+            test_pending<COUNT>(L, tris, pend, n, lo, ld, n_tri);
+        }
+        tm = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
     }
-}
-
-// Closest hit over the rays of a (sharded) queue (scene.rs:190-208), workgroup-cooperative and persistent:
-//  phase 1 (all lanes, uniform control flow): every analytic instance (sphere / plane) in visiting order, plus the
-//          root-box test of the mesh instances; a ray that enters a mesh box is queued in LDS instead of traversed
-//  phase 2 (whenever HPT_BLOCK rays are queued): one queued ray per lane -> every lane of every wave walks a BVH
-//  Rays are identified by their slot i; results go to hit[i] / hit_inst[i] exactly once per ray.
-template <bool COUNT, bool NODE32>
-__device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
-                                                  const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
-                                                  unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) { *L.qn = 0; *L.qhead = 0; }
-    __syncthreads();
-    const uint32_t total = work_items(wv);
-    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
-        uint32_t i;
-        const bool valid = work_slot(wv, w, i);
-        bool queued = false;
-        uint2 item = make_uint2(0, 0);
-        if (valid) {
-            Hit h;
-            queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, h, item, n_inst);
-            hit[i] = make_float4(h.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = h.inst_side;   // final for unqueued rays, interim otherwise
-        }
-        // append the queued rays: 64-bit ballot + prefix popcount, one LDS atomic per wave
-        const unsigned long long mask = __ballot(queued);
-        if (mask) {
-            unsigned wbase = 0;
-            if (lane == 0) wbase = atomicAdd(L.qn, (unsigned)__popcll(mask));
-            wbase = __shfl(wbase, 0);
-            if (queued) L.queue[wbase + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = item;
-        }
-        __syncthreads();
-        const unsigned cnt = *L.qn;
-        if (cnt > HPT_QUEUE_CAP - HPT_BLOCK) {      // the next chunk might not fit: drain everything (workgroup-uniform)
-            drain_queue<COUNT, NODE32>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
-            __syncthreads();
-            if (threadIdx.x == 0) { *L.qn = 0; *L.qhead = 0; }
-            __syncthreads();
-        }
-    }
-    const unsigned cnt = *L.qn;
-    if (cnt) drain_queue<COUNT, NODE32>(sc, L, cnt, ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
 }
 
 // ------------------------------------------------------------------------------------------------ two-level traversal
@@ -1133,7 +1216,8 @@ static inline int grid_for(uint64_t n, int max_blocks) {
 }
 // dynamic LDS of the traversal kernels: stack + node cache + work queue + queue counter (see lds_carve)
 static inline size_t trav_lds_bytes(int stack_entries, bool with_queue = true) {
-    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16 + (with_queue ? HPT_QUEUE_CAP * sizeof(uint2) : 0);
+    return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16 +
+           (with_queue ? HPT_QUEUE_CAP * sizeof(uint2) + (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 : 0);
 }
 
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
@@ -1154,7 +1238,7 @@ void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& 
     hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
 }
 size_t hptk_extend_lds_bytes(int stack_entries, bool tlas) { return trav_lds_bytes(stack_entries, !tlas); }
-static int g_refill = 16;
+static int g_refill = 24;
 void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
     const size_t lds = trav_lds_bytes(stack_entries, !sc.use_tlas);

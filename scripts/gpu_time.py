@@ -40,7 +40,7 @@ def main():
                 for r in [int(c) for c in w[1:].split(",")]:
                     hpt.lib.hpt_debug_set_refill(r)
                     run("refill %d (rep %d)" % (r, rep), d)
-            hpt.lib.hpt_debug_set_refill(16)
+            hpt.lib.hpt_debug_set_refill(24)
         elif w.startswith("B"):
             for b in [int(c) for c in w[1:].split(",")]:
                 run("blocks/CU %d" % b, d, bpc=b)
