@@ -705,15 +705,18 @@ static int default_spp_per_pass(uint64_t npix, int want) {
 }
 
 // one wavefront pass: raygen -> [extend -> shade]* -> resolve, all asynchronous on the context stream
-// Persistent grid of k_extend: as many workgroups per CU as its register budget allows (5 waves/SIMD for the linear
-// kernel, 4 for the two-level one -- hpt_kernels.hip) and as fit into the CU's 160 KB of LDS.
+// Persistent grid of k_extend: exactly the workgroups the device keeps resident (registers and LDS of the variant that
+// runs: the occupancy query) -- work is strided statically over the grid, so a workgroup that had to wait for a free
+// slot would start its share when the others are done.
 static int extend_grid(const hpt_scene* s) {
     const hpt_context* ctx = s->ctx;
-    int per_cu = ctx->extend_per_cu > 0 ? ctx->extend_per_cu : (s->ds.use_tlas ? 4 : 5) * 256 / HPT_BLOCK;
-    const size_t lds = hptk_extend_lds_bytes(s->stack_entries, s->ds.use_tlas != 0);
-    const int fit = (int)((160u * 1024u) / std::max<size_t>(lds, 1));
-    per_cu = std::max(1, std::min(per_cu, fit));
-    return ctx->num_cus * per_cu;
+    int per_cu = ctx->extend_per_cu;
+    if (per_cu <= 0) per_cu = hptk_extend_blocks_per_cu(s->stack_entries, s->ds);
+    if (per_cu <= 0) {      // query failed: register budget of the kernels (hpt_kernels.hip) and LDS fit
+        const size_t lds = hptk_extend_lds_bytes(s->stack_entries, s->ds.use_tlas != 0);
+        per_cu = std::min(4, (int)((160u * 1024u) / std::max<size_t>(lds, 1)));
+    }
+    return ctx->num_cus * std::max(1, per_cu);
 }
 
 static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks) {

@@ -35,9 +35,10 @@
 #endif
 #define HPT_COUNTS_PER_DEPTH (HPT_SHARDS * HPT_COUNT_STRIDE)
 #ifndef HPT_QUEUE_CAP
-#define HPT_QUEUE_CAP 1024
+#define HPT_QUEUE_CAP 512
 #endif
-//      HPT_QUEUE_CAP         // LDS work queue of k_extend: rays that entered a mesh box, waiting for traversal
+//      HPT_QUEUE_CAP         // LDS ray rings of k_extend, one per wave (HPT_QUEUE_CAP / 4 items each: < 64 left + 64 appended):
+//                            // rays that entered a mesh box, waiting for traversal
 
 struct DMesh {
     int32_t root_ref;     // ref of the root (interior index or ~tri for a one-triangle mesh)

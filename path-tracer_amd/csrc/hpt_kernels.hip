@@ -21,7 +21,7 @@
 #define PI_F 3.14159265358979323846f
 // register budgets (waves per SIMD the allocator must reach) of the two hot kernels; see DESIGN.md tuning log
 #ifndef HPT_EXTEND_WAVES
-#define HPT_EXTEND_WAVES 4       // linear-instance-list kernel: 90 VGPRs; the two-level kernel (116 VGPRs) stays at 4
+#define HPT_EXTEND_WAVES 5       // linear-instance-list kernel: 90 VGPRs; the two-level kernel (116 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 5
@@ -392,7 +392,7 @@ __device__ __forceinline__ void test_pending(const Lds& L, const float4* __restr
 // x = global wave, + number of waves, ...) and alternates between two kinds of work.
 //  phase 1 (all 64 lanes, uniform control flow): every analytic instance (sphere / plane) in visiting order, plus the
 //          root-box test of the first mesh instance the ray enters; such a ray is appended to the wave's LDS queue
-//          (ring of HPT_QUEUE_CAP / 4 items) instead of being traversed; runs whenever fewer than 64 rays are queued
+//          (ring of HPT_QUEUE_CAP / 4 = 128 items) instead of being traversed; runs whenever fewer than 64 rays are queued
 //  phase 2 (persistent lanes): a lane owns one queued ray at a time: it walks the BVHs of the mesh instances that ray
 //          still has to visit (trace order = visiting order) and writes the final hit record.  The inner loop is
 //          nothing but box steps: a child that is a leaf and whose box the ray enters is not walked into but appended
@@ -436,7 +436,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     bool have = false;
     uint32_t slot = 0; int mpos = 0, first_mpos = 0;
     f3 lo = mk3(0, 0, 0), ld = mk3(0, 0, 1);
-    Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+    float ht = HPT_INF; uint32_t hinst = HPT_MISS_INST;      // scene-level nearest so far of the lane's ray (t, instance | side)
     RayBox rb = make_raybox(lo, ld);
     float tm = HPT_INF; int ref = SENTINEL, sp = 1, inst_idx = 0;
     for (;;) {
@@ -472,9 +472,9 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 if (!have && rank < avail) {
                     const uint2 it = queue[(qhead + rank) & (QW - 1u)];
                     slot = it.x; mpos = first_mpos = (int)it.y;
-                    // 8-byte items keep the queues at 8 KB of LDS; the best analytic hit of phase 1 comes back from
+                    // 8-byte items keep the rings at 4 KB of LDS; the best analytic hit of phase 1 comes back from
                     // hit[] / hit_inst[] (L2-resident)
-                    h.t = hit[slot].x; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = hit_inst[slot];
+                    ht = hit[slot].x; hinst = hit_inst[slot];
                     have = true; need_setup = true;
                 }
                 const unsigned nidle = (unsigned)__popcll(idle);
@@ -490,11 +490,14 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 const float t = __uint_as_float((uint32_t)(key >> 32));
                 // replaces the scene-level nearest iff t < h.t, or t == h.t and this instance comes EARLIER in the
                 // reference's visiting order than the holder of h.t (scene.rs:196,251 keep the earlier node on equal t)
-                const bool tie_ok = (uint32_t)inst_idx < (h.inst_side & 0x7fffffffu);
-                if (t < h.t || (tie_ok && t == h.t)) {
+                const bool tie_ok = (uint32_t)inst_idx < (hinst & 0x7fffffffu);
+                if (t < ht || (tie_ok && t == ht)) {
+                    // the record in hit[] is brought up to date right away: only t and the instance stay in registers
                     const uint32_t sf = L.dsf[threadIdx.x];
-                    h.t = (sf & 2u) ? -0.0f : t; h.u = L.du[threadIdx.x]; h.v = L.dv[threadIdx.x]; h.prim = (int)(uint32_t)key;
-                    h.inst_side = (uint32_t)inst_idx | ((sf & 1u) << 31);
+                    ht = (sf & 2u) ? -0.0f : t;
+                    hinst = (uint32_t)inst_idx | ((sf & 1u) << 31);
+                    hit[slot] = make_float4(ht, L.du[threadIdx.x], L.dv[threadIdx.x], __int_as_float((int)(uint32_t)key));
+                    hit_inst[slot] = hinst;
                 }
             }
             ++mpos;
@@ -504,12 +507,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
         if (need_setup) {
             const f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
             for (;;) {
-                if (mpos >= sc.n_mesh_instances) {
-                    hit[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
-                    hit_inst[slot] = h.inst_side;
-                    have = false; ref = SENTINEL;
-                    break;
-                }
+                if (mpos >= sc.n_mesh_instances) { have = false; ref = SENTINEL; break; }      // hit[slot] is final
                 inst_idx = sc.mesh_instances[mpos];
                 const DInstance* in = sc.instances + inst_idx;
                 lo = o; ld = d;
@@ -523,7 +521,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 const DMesh* mesh = sc.meshes + in->mesh;
                 rb = make_raybox(lo, ld);
                 float tin;
-                if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), h.t, tin)) {
+                if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), ht, tin)) {
                     if (NODE32) rb = quant_slab(rb, mesh->qbase, mesh->qscale);   // from here on rb addresses the tree's 16-bit grid
                     tm = HPT_INF; *mybest = HPT_KEY_NONE;
                     stk[0] = SENTINEL; sp = 1; ref = mesh->root_ref;
@@ -543,7 +541,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             if (ref >= 0) {
                 if (COUNT) n_int++;
                 bool hitL, hitR; float tinL, tinR;
-                test_children<NODE32>(nodes, ref, rb, fminf(tm, h.t), hitL, hitR, tinL, tinR, l, r);
+                test_children<NODE32>(nodes, ref, rb, fminf(tm, ht), hitL, hitR, tinL, tinR, l, r);
                 leafL = hitL && l < 0; leafR = hitR && r < 0;
                 const bool intL = hitL && l >= 0, intR = hitR && r >= 0;
                 if (intL && intR) {
@@ -1214,6 +1212,9 @@ static inline int grid_for(uint64_t n, int max_blocks) {
     if (b > (uint64_t)max_blocks) b = (uint64_t)max_blocks;
     return (int)b;
 }
+// stack entries the traversal kernels carve: the instance-list path never pushes a leaf (leaf children go to the pending
+// list), so it needs one entry less than traverse_mesh / the two-level path, whose count the host hands over
+static inline int carve_entries(int stack_entries, bool tlas) { return tlas ? stack_entries : (stack_entries > 2 ? stack_entries - 1 : stack_entries); }
 // dynamic LDS of the traversal kernels: stack + node cache + work queue + queue counter (see lds_carve)
 static inline size_t trav_lds_bytes(int stack_entries, bool with_queue = true) {
     return (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16 +
@@ -1231,16 +1232,31 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
                           float4* pos, float4* normal, float4* uvw) {
     const int grid = grid_for((uint64_t)n, max_blocks);
+    stack_entries = carve_entries(stack_entries, sc.use_tlas != 0);
     hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries, !sc.use_tlas), st, sc, n, org, dir, hit, hit_inst, stack_entries);
     hipLaunchKernelGGL(k_scene_hitinfo, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, node, prim, t, side, pos, normal, uvw);
 }
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
 }
-size_t hptk_extend_lds_bytes(int stack_entries, bool tlas) { return trav_lds_bytes(stack_entries, !tlas); }
+size_t hptk_extend_lds_bytes(int stack_entries, bool tlas) { return trav_lds_bytes(carve_entries(stack_entries, tlas), !tlas); }
+template <typename K>
+static int resident_blocks(K k, size_t lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, HPT_BLOCK, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+// workgroups of k_extend one CU keeps resident (registers and LDS of the variant that will be launched): the grid of a
+// persistent kernel with statically strided work must not exceed it, or the surplus workgroups start when the others end
+int hptk_extend_blocks_per_cu(int stack_entries, const DScene& sc) {
+    const size_t lds = hptk_extend_lds_bytes(stack_entries, sc.use_tlas != 0);
+    return sc.use_tlas ? (sc.node32 ? resident_blocks(k_extend<false, true, true>, lds) : resident_blocks(k_extend<false, true, false>, lds))
+                       : (sc.node32 ? resident_blocks(k_extend<false, false, true>, lds) : resident_blocks(k_extend<false, false, false>, lds));
+}
 static int g_refill = 24;
 void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
 void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
+    stack_entries = carve_entries(stack_entries, sc.use_tlas != 0);
     const size_t lds = trav_lds_bytes(stack_entries, !sc.use_tlas);
     // one kernel per (instrumented, two-level) combination: each path gets its own register allocation
     auto k = sc.use_tlas ? (sc.node32 ? (count ? k_extend<true, true, true> : k_extend<false, true, true>) : (count ? k_extend<true, true, false> : k_extend<false, true, false>))
