@@ -317,6 +317,19 @@ __device__ __forceinline__ bool work_slot(const WorkView& wv, uint32_t w, uint32
     return off < cnt;
 }
 
+// number of 64-slot input pieces a launch has to look at: none beyond the fullest segment
+__device__ __forceinline__ uint32_t input_pieces(const WorkView& wv) {
+    const unsigned lane = threadIdx.x & 63u;
+    uint32_t maxcnt = wv.n_linear;
+    if (wv.counts) {
+        maxcnt = lane < wv.shards ? wv.counts[lane * HPT_COUNT_STRIDE] : 0u;
+        for (unsigned k = lane + 64u; k < wv.shards; k += 64u) maxcnt = max(maxcnt, wv.counts[k * HPT_COUNT_STRIDE]);
+        for (int off = 32; off > 0; off >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor((int)maxcnt, off));
+    }
+    maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+    return wv.shards * ((maxcnt + HPT_BLOCK - 1) / HPT_BLOCK) * (HPT_BLOCK / 64);
+}
+
 // phase 1 for one ray: analytic instances + first mesh box entered.  Returns true when the ray must be queued.
 template <bool COUNT>
 __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uint32_t slot, Hit& h, uint2& item, unsigned& n_inst) {
@@ -421,15 +434,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     const int SENTINEL = (int)0x80000000;
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
-    // input pieces: none beyond the fullest segment
-    uint32_t maxcnt = wv.n_linear;
-    if (wv.counts) {
-        maxcnt = lane < wv.shards ? wv.counts[lane * HPT_COUNT_STRIDE] : 0u;
-        for (unsigned k = lane + 64u; k < wv.shards; k += 64u) maxcnt = max(maxcnt, wv.counts[k * HPT_COUNT_STRIDE]);
-        for (int off = 32; off > 0; off >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor((int)maxcnt, off));
-    }
-    maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
-    const uint32_t total = wv.shards * ((maxcnt + HPT_BLOCK - 1) / HPT_BLOCK) * WAVES;
+    const uint32_t total = input_pieces(wv);
     const uint32_t xstep = gridDim.x * WAVES;
     uint32_t x = blockIdx.x * WAVES + wave;
     unsigned qn = 0, qhead = 0, pend = 0;                // wave-uniform: ring counters (monotonic), pending-list fill
@@ -587,16 +592,25 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
 // smaller, which is the reference's rule "strictly nearer wins, earlier node wins ties" (scene.rs:196,251).
 #define HPT_INST_BASE 0x40000000
 #define HPT_REF_RESTORE ((int)~0x7ffffffe)
+// Every wave is a persistent worker of its own (no workgroup barrier): it walks the 64-slot pieces x = global wave,
+// + number of waves, ... of the input (piece x = quarter x % 4 of chunk x / 4) and hands their rays to lanes as they
+// fall idle, so under-filled steps only occur at the very end of the launch.
 template <bool COUNT, bool NODE32>
-__device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, uint32_t base_slot, uint32_t n_valid,
-                                                const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
-                                                unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+__device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
+                                                       const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
+                                                       unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+    constexpr unsigned WAVES = HPT_BLOCK / 64;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
     int* stk = L.stack + threadIdx.x;
     const int SENTINEL = (int)0x80000000;
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
-    bool have = false, exhausted = false;
+    const uint32_t total = input_pieces(wv);
+    const uint32_t xstep = gridDim.x * WAVES;
+    uint32_t x = blockIdx.x * WAVES + wave;
+    uint32_t piece_slot = 0, piece_n = 0, piece_pos = 0;      // wave-uniform: the piece rays are being handed out from
+    bool have = false, input_done = false;
     uint32_t slot = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), co = o, cd = d;
     Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
@@ -608,25 +622,37 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
             hit_inst[slot] = h.inst_side;
             have = false;
         }
-        if (!exhausted) {
-            bool tried = false;
-            if (!have) {
-                tried = true;
-                const unsigned idx = atomicAdd(L.qhead, 1u);
-                if (idx < n_valid) {
-                    slot = base_slot + idx;
-                    o = xyz(ray_o[slot]); d = xyz(ray_d[slot]); co = o; cd = d;
-                    rb = make_raybox(o, d);
-                    if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
-                    h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
-                    stk[0] = SENTINEL; sp = 1; ref = sc.tlas_root;
-                    have = true;
+        // ---- idle lanes take the next rays of the input
+        while (!input_done) {
+            const unsigned long long idle = __ballot(!have);
+            if (idle == 0ull) break;
+            if (piece_pos >= piece_n) {
+                bool found = false;
+                while (x < total) {
+                    const uint32_t w = x / WAVES, sub = x % WAVES;
+                    x += xstep;
+                    const uint32_t seg = w % wv.shards, k = w / wv.shards;
+                    const uint32_t cnt = wv.counts ? wv.counts[seg * HPT_COUNT_STRIDE] : wv.n_linear;
+                    const uint32_t off0 = k * HPT_BLOCK + sub * 64u;
+                    if (off0 < cnt) { piece_slot = seg * wv.cap + off0; piece_n = min(64u, cnt - off0); piece_pos = 0; found = true; break; }
                 }
+                if (!found) { input_done = true; break; }
             }
-            exhausted = __ballot(tried && !have) != 0ull;
+            const uint32_t left = piece_n - piece_pos, nidle = (uint32_t)__popcll(idle), take = nidle < left ? nidle : left;
+            const uint32_t rank = (uint32_t)__popcll(idle & below);
+            if (!have && rank < take) {
+                slot = piece_slot + piece_pos + rank;
+                o = xyz(ray_o[slot]); d = xyz(ray_d[slot]); co = o; cd = d;
+                rb = make_raybox(o, d);
+                if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
+                h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+                stk[0] = SENTINEL; sp = 1; ref = sc.tlas_root;
+                have = true;
+            }
+            piece_pos += take;
         }
-        if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
-        const int keep_going_above = exhausted ? 0 : 64 - L.refill;
+        if (__ballot(have) == 0ull) break;      // only possible once the input is used up
+        const int keep_going_above = input_done ? 0 : 64 - L.refill;
         while (__popcll(__ballot(have && ref != SENTINEL)) > keep_going_above) {
             if (!have) continue;
             if (ref >= 0) {
@@ -691,25 +717,6 @@ __device__ __forceinline__ void drain_rays_tlas(const DScene& sc, const Lds& L, 
                 ref = stk[sp * HPT_BLOCK];
             }
         }
-    }
-}
-
-// closest hit over a (sharded) queue through the TLAS: a workgroup takes groups of 4 chunks (1024 slots) so that lanes
-// that finish early find more rays to pull
-template <bool COUNT, bool NODE32>
-__device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
-                                                       const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
-                                                       unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
-    const uint32_t GROUP = 4 * HPT_BLOCK;
-    const uint32_t groups_per_seg = (wv.cap + GROUP - 1) / GROUP, total = wv.shards * groups_per_seg;
-    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
-        const uint32_t s = w % wv.shards, g = w / wv.shards;
-        const uint32_t cnt = wv.counts ? wv.counts[s * HPT_COUNT_STRIDE] : wv.n_linear;
-        const uint32_t first = g * GROUP;
-        if (threadIdx.x == 0) *L.qhead = 0;
-        __syncthreads();
-        if (first < cnt) drain_rays_tlas<COUNT, NODE32>(sc, L, s * wv.cap + first, min(GROUP, cnt - first), ray_o, ray_d, hit, hit_inst, n_int, n_tri, n_inst);
-        __syncthreads();
     }
 }
 
