@@ -160,7 +160,7 @@ __device__ __forceinline__ bool intersect_plane(f3 pos, f3 dir, float& t, int& s
 // into the coefficients: t(q) = q * (qscale * a) + (qbase * a + b), so a quantised box costs the same 12 fma.
 //
 // The test must never cull a box the exact arithmetic enters (hits are decided by the exact primitive tests, boxes
-// only prune).  Two roundings matter: a = fl(1/d) scales every t by (1 +- 2^-24) -- covered by the relative 1e-6 on
+// only prune).  Two roundings matter: a = rcp(d) scales every t by (1 +- 2^-23) -- covered by the relative 1e-6 on
 // t_out and on the bound -- and b = fl(o * a) is off by half an ulp of |b|, an ABSOLUTE error in t that no relative
 // slack covers when the ray starts far from the origin of the space but close to the box (|b| >> |t|).  So each axis
 // keeps TWO offsets, blo = b - e and bhi = b + e with e = 2^-22 |b| (Node32: plus the rounding of the folded grid
@@ -172,7 +172,8 @@ __device__ __forceinline__ float safe_dir(float v) { return fabsf(v) < 1.0e-30f 
 #define HPT_SLAB_EPS 2.4e-7f   // 2^-22
 __device__ __forceinline__ Slab make_raybox(f3 o, f3 d) {
     Slab r;
-    r.ax = 1.0f / safe_dir(d.x); r.ay = 1.0f / safe_dir(d.y); r.az = 1.0f / safe_dir(d.z);
+    // hardware reciprocal (1 ulp): culling only, its error is inside the relative slack of slab_hit
+    r.ax = __builtin_amdgcn_rcpf(safe_dir(d.x)); r.ay = __builtin_amdgcn_rcpf(safe_dir(d.y)); r.az = __builtin_amdgcn_rcpf(safe_dir(d.z));
     const float bx = -(o.x * r.ax), by = -(o.y * r.ay), bz = -(o.z * r.az);
     const float ex = HPT_SLAB_EPS * fabsf(bx), ey = HPT_SLAB_EPS * fabsf(by), ez = HPT_SLAB_EPS * fabsf(bz);
     r.blx = bx - ex; r.bly = by - ey; r.blz = bz - ez;
