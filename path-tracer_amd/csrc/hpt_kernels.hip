@@ -21,7 +21,7 @@
 #define PI_F 3.14159265358979323846f
 // register budgets (waves per SIMD the allocator must reach) of the two hot kernels; see DESIGN.md tuning log
 #ifndef HPT_EXTEND_WAVES
-#define HPT_EXTEND_WAVES 5       // linear-instance-list kernel: 90 VGPRs; the two-level kernel (116 VGPRs) stays at 4
+#define HPT_EXTEND_WAVES 5       // instance-list kernel: 96 VGPRs (a few spills in the refill path); the two-level kernel (111 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 5
@@ -1232,7 +1232,7 @@ static inline size_t trav_lds_bytes(int stack_entries, bool with_queue = true) {
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
                      const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat) {
     const int grid = grid_for((uint64_t)n, max_blocks);
-    const size_t lds = trav_lds_bytes(mesh.stack_need);
+    const size_t lds = trav_lds_bytes(mesh.stack_need, false);      // the stack only
     auto k = sc.node32 ? (count ? k_trace_rays<true, true> : k_trace_rays<false, true>) : (count ? k_trace_rays<true, false> : k_trace_rays<false, false>);
     hipLaunchKernelGGL(k, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, sc.n_nodes, mesh.stack_need, mesh, n, org, dir, hit, side, stat);
 }

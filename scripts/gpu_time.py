@@ -12,7 +12,8 @@ def run(name, desc, tree=True, spp=16, S=4, depth=8, bpc=None):
     sc = hpt.Scene(ctx, desc, host_bvh=(lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if tree else None)
     out = torch.zeros(desc.camera.width * desc.camera.height * 3, device="cuda")
     sc.render_device(out.data_ptr(), want_stats=True, spp=4, max_depth=depth, seed=1, spp_per_pass=S)
-    cst = sc.render_device(out.data_ptr(), want_stats=True, spp=4, max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_COUNTERS)
+    cspp = int(os.environ.get("HPT_TIME_COUNTER_SPP", "4"))      # samples of the instrumented run (its pass size changes the tail share)
+    cst = sc.render_device(out.data_ptr(), want_stats=True, spp=cspp, max_depth=depth, seed=1, spp_per_pass=max(S, cspp), flags=hpt.RENDER_COUNTERS)
     st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_TIME_KERNELS)
     rays = st.rays_primary + st.rays_bounce; cr = cst.rays_primary + cst.rays_bounce
     print("%-28s total %.3fs %7.1f Mrays/s | extend %.4f (%.2f Grays/s) shade %.4f | nodes/ray %.2f tris/ray %.2f inst/ray %.1f" % (
