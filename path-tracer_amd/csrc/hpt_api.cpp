@@ -471,7 +471,13 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         if (!flatten_tree(tt, wb.data(), (int32_t)inst.size(), ft, err)) return fail(HPT_ERR_INVALID, "%s", err.c_str());
         const int64_t node_base = (int64_t)(nodes.size() / 16);
         if (node_base + ft.n_interior >= (1ll << 31)) return fail(HPT_ERR_LIMIT, "scene: more than 2^31 nodes");
-        auto rebase = [&](int32_t ref) -> int32_t { return ref >= 0 ? (int32_t)(ref + node_base) : ~(int32_t)(0x40000000 + (~ref)); };
+        // leaf refs: ~(0x40000000 + i) for a mesh instance, ~(0x60000000 + i) for a sphere / plane (the kernel defers those)
+        if (inst.size() >= (1u << 26)) return fail(HPT_ERR_LIMIT, "scene: more than 2^26 instances");
+        auto rebase = [&](int32_t ref) -> int32_t {
+            if (ref >= 0) return (int32_t)(ref + node_base);
+            const int32_t i = ~ref;
+            return ~(int32_t)((inst[(size_t)i].geom == HPT_GEOM_MESH ? 0x40000000 : 0x60000000) + i);
+        };
         for (int32_t i = 0; i < ft.n_interior; ++i) {
             int32_t l, r;
             std::memcpy(&l, &ft.nodes[(size_t)i * 16 + 3], 4); std::memcpy(&r, &ft.nodes[(size_t)i * 16 + 7], 4);
@@ -713,7 +719,7 @@ static int extend_grid(const hpt_scene* s) {
     int per_cu = ctx->extend_per_cu;
     if (per_cu <= 0) per_cu = hptk_extend_blocks_per_cu(s->stack_entries, s->ds);
     if (per_cu <= 0) {      // query failed: register budget of the kernels (hpt_kernels.hip) and LDS fit
-        const size_t lds = hptk_extend_lds_bytes(s->stack_entries, s->ds.use_tlas != 0);
+        const size_t lds = hptk_extend_lds_bytes(s->stack_entries, s->ds);
         per_cu = std::min(4, (int)((160u * 1024u) / std::max<size_t>(lds, 1)));
     }
     return ctx->num_cus * std::max(1, per_cu);
