@@ -441,7 +441,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     int32_t use_tlas = 0, tlas_root = 0;
     s->tlas_nodes = 0;
     QuantFrame tlas_qf; std::memset(&tlas_qf, 0, sizeof tlas_qf);
-    if ((int)inst.size() >= tlas_min && !inst.empty()) {
+    if ((int)inst.size() >= tlas_min && inst.size() >= 2) {      // (>= 2: the root of the TLAS is an interior node)
         std::vector<float> wb(inst.size() * 6);
         for (size_t i = 0; i < inst.size(); ++i) {
             const DInstance& di = inst[i];

@@ -742,8 +742,9 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
                 } else if (ref == HPT_REF_RESTORE) {          // back from a mesh instance to the world-space ray
                     co = o; cd = d; rb = make_raybox(o, d);
                     if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
-                } else {                                      // TLAS leaf: a mesh instance (or an analytic one that is the root)
-                    const uint32_t i = x >= (uint32_t)HPT_ANALYTIC_BASE ? x - (uint32_t)HPT_ANALYTIC_BASE : x - (uint32_t)HPT_INST_BASE;
+                } else {                                      // TLAS leaf: an instance (DEFER: a mesh instance -- analytic ones
+                                                              // never reach the stack, the TLAS root is an interior node)
+                    const uint32_t i = (!DEFER && x >= (uint32_t)HPT_ANALYTIC_BASE) ? x - (uint32_t)HPT_ANALYTIC_BASE : x - (uint32_t)HPT_INST_BASE;
                     const DInstance* in = sc.instances + i;
                     f3 lo = o, ld = d;
                     ray_level(in->lv[0], lo, ld);
@@ -753,7 +754,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
                         for (int k = 2; k < nlev; ++k) ray_level(sc.xinv[in->xf_first + k], lo, ld);
                     }
                     if (COUNT) n_inst++;
-                    const int geom = in->geom;
+                    const int geom = DEFER ? 3 : in->geom;
                     if (geom == 3) {
                         const DMesh* mesh = sc.meshes + in->mesh;
                         const RayBox lrb = make_raybox(lo, ld);
