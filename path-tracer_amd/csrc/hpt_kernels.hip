@@ -610,6 +610,9 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
 // << 26 | instance), one per lane.  The tester fetches the owner's WORLD ray through the LDS crossbar, walks the
 // instance's transform chain, runs the exact sphere / plane test and merges a hit into the owner's key with a 64-bit
 // LDS min: t bits << 32 | instance << 1 | side -- nearest hit, the earlier instance on equal t (scene.rs:196,251).
+#ifndef HPT_PARK
+#define HPT_PARK 12
+#endif
 #define HPT_ANALYTIC_BASE 0x60000000      // TLAS leaf refs: ~(HPT_INST_BASE + i) mesh instance, ~(HPT_ANALYTIC_BASE + i) sphere / plane
 template <bool COUNT>
 __device__ __forceinline__ void test_pending_analytic(const DScene& sc, const Lds& L, unsigned first, unsigned n, f3 o, f3 d, unsigned& n_inst) {
@@ -653,6 +656,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
     const uint32_t xstep = gridDim.x * WAVES;
     uint32_t x = blockIdx.x * WAVES + wave;
     uint32_t piece_slot = 0, piece_n = 0, piece_pos = 0;      // wave-uniform: the piece rays are being handed out from
+    const bool park = sc.n_mesh_instances > 0;
     unsigned long long* mybest = L.best + threadIdx.x;        // best analytic hit of the lane's ray: t bits << 32 | instance << 1 | side
     const unsigned lbase = wave * HPT_LEAF_CAP;
     unsigned pend = 0;                                        // wave-uniform: analytic instances waiting to be tested
@@ -709,6 +713,18 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
         const int keep_going_above = input_done ? 0 : 64 - L.refill;
         while (__popcll(__ballot(have && ref != SENTINEL)) > keep_going_above) {
             bool anaL = false, anaR = false; int l = 0, r = 0;
+            // Parking: a lane that holds a triangle or an instance leaf waits until HPT_PARK lanes of the wave hold the same
+            // kind (or no lane has a box step left), so the long, rarely needed blocks run in few steps with many lanes
+            // instead of in every step with three or four.
+            const bool at_leaf = have && ref < 0 && ref != SENTINEL;
+            const bool at_tri = at_leaf && (uint32_t)~ref < (uint32_t)HPT_INST_BASE;
+            const bool at_inst = at_leaf && !at_tri && ref != HPT_REF_RESTORE;
+            bool go_tri = true, go_inst = true;
+            if (park) {      // (scenes without mesh instances have nothing worth waiting for)
+                const bool no_box_step = __ballot(have && ref >= 0) == 0ull;
+                go_tri = no_box_step || __popcll(__ballot(at_tri)) >= HPT_PARK;
+                go_inst = no_box_step || __popcll(__ballot(at_inst)) >= HPT_PARK;
+            }
             if (have && ref >= 0) {
                 if (COUNT) n_int++;
                 bool hitL, hitR; float tinL, tinR;
@@ -725,7 +741,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
                 } else if (hitL) ref = l;
                 else if (hitR) ref = r;
                 else { --sp; ref = stk[sp * HPT_BLOCK]; }
-            } else if (have && ref != SENTINEL) {
+            } else if (at_leaf && (at_tri ? go_tri : (at_inst ? go_inst : true))) {
                 const uint32_t x = (uint32_t)~ref;
                 bool pop = true;
                 if (x < (uint32_t)HPT_INST_BASE) {            // triangle of the mesh instance being walked
