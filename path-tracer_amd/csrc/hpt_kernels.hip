@@ -14,6 +14,7 @@
 // boxes are conservative supersets of their triangles).  MFMA is not used: there is no dense contraction here.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <stdint.h>
 #include "hpt_device.h"
 #include "hpt_launch.h"
@@ -28,6 +29,10 @@
 #endif
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
+// lanes of a wave that must hold a leaf of one kind before its block runs (two-level kernel), see DESIGN.md
+#ifndef HPT_PARK
+#define HPT_PARK 12
+#endif
 
 // ------------------------------------------------------------------------------------------------ vector helpers
 struct f3 { float x, y, z; };
@@ -232,53 +237,6 @@ __device__ __forceinline__ void test_children(const float4* __restrict__ nodes, 
     }
 }
 
-// Closest hit of one ray against one mesh (geometry.rs:132-158 + bvh.rs:148-204).
-//  - candidate accepted iff t <= tm (later candidate wins ties inside a mesh, geometry.rs:142-146) and it would
-//    replace the scene-level nearest: t < tlimit, or t == tlimit when this instance comes EARLIER in the reference's
-//    visiting order than the holder of tlimit (tie_ok; scene.rs:196,251 keep the earlier node on equal t)
-//  - stk: this lane's column of the LDS stack (stride HPT_BLOCK ints)
-template <bool COUNT, bool NODE32>
-__device__ __forceinline__ void traverse_mesh(const float4* __restrict__ nodes, const float4* __restrict__ tris, const DMesh& mesh,
-                                              f3 o, f3 d, float tlimit, bool tie_ok,
-                                              float& tm, int& prim, float& bu, float& bv, int& side,
-                                              int* stk, unsigned& n_int, unsigned& n_tri) {
-    const Slab rb = make_raybox(o, d);
-    const Slab ns = NODE32 ? quant_slab(rb, mesh.qbase, mesh.qscale) : rb;
-    const int SENTINEL = (int)0x80000000;      // bottom of the stack: a "leaf" ref no triangle can have
-    stk[0] = SENTINEL;
-    int sp = 1;
-    int ref = mesh.root_ref;
-    // if-if loop.  (A while-while loop -- inner loop over interior nodes until every lane holds a leaf -- measured 47 %
-    // SLOWER here: leaves hold one triangle, so lanes that reach a leaf early idle; a reciprocal pre-filter in front of the
-    // triangle test's three IEEE divisions measured +-0: see DESIGN.md tuning log.)
-    while (ref != SENTINEL) {
-        if (ref >= 0) {
-            if (COUNT) n_int++;
-            bool hitL, hitR; float tinL, tinR; int l, r;
-            test_children<NODE32>(nodes, ref, ns, fminf(tm, tlimit), hitL, hitR, tinL, tinR, l, r);
-            if (hitL && hitR) {
-                const bool lfirst = tinL < tinR;
-                stk[sp * HPT_BLOCK] = lfirst ? r : l;
-                sp++;
-                ref = lfirst ? l : r;
-            } else if (hitL) ref = l;
-            else if (hitR) ref = r;
-            else { --sp; ref = stk[sp * HPT_BLOCK]; }
-        } else {
-            const int tri = ~ref;
-            const float4* tq = tris + (uint32_t)tri * (uint32_t)HPT_TRI_QUADS;
-            const float4 a = tq[0], ab = tq[1], ac = tq[2];
-            if (COUNT) n_tri++;
-            float t, u, v; int s;
-            if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), o, d, t, u, v, s)) {
-                if ((t < tm || (t == tm && tri < prim)) && (t < tlimit || (tie_ok && t == tlimit))) { tm = t; prim = tri; bu = u; bv = v; side = s; }
-            }
-            --sp;
-            ref = stk[sp * HPT_BLOCK];
-        }
-    }
-}
-
 struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 
 // ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
@@ -381,7 +339,8 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
 // Deferred triangle tests of one wave: entries [first, first + n) of its pending list, one per lane (n <= 64, uniform).
 // The tester lane fetches the owner lane's mesh-local ray through the LDS crossbar, runs the exact triangle test and
 // merges a hit into the owner's key with a 64-bit LDS min: key = t bits << 32 | triangle, so the minimum is the nearest
-// hit and, on equal t, the lower triangle index (the order-independent tie rule of traverse_mesh).  The lane whose key
+// hit and, on equal t, the lower triangle index (order-independent, hence deterministic; the reference's "later visited wins" depends on its
+// own tree and north_star excludes edge rays).  The lane whose key
 // is the minimum afterwards leaves u, v and the side beside it (LDS operations of one wave execute in order).
 #define HPT_KEY_NONE 0x7f800000ffffffffull      // t = +inf, no triangle
 template <bool COUNT>
@@ -434,10 +393,13 @@ __device__ __forceinline__ void test_pending(const Lds& L, const float4* __restr
 // end of the launch (node visits per ray are heavy-tailed, 20..300: when the queue was drained to the last ray before
 // each refill -- the first version -- every drain ended in such a tail and half of all lane-steps were idle).
 // Rays are identified by their slot i; results go to hit[i] / hit_inst[i] exactly once per ray.
-template <bool COUNT, bool NODE32>
+// LOCAL (the Mesh::intersect test entry, k_trace_rays): rays are given in the space of ONE mesh, `lmesh`; phase 1 is its
+// root-box test alone, and the result is hit[i] = (t, u, v, triangle index inside the mesh | -1), side_out[i].
+template <bool COUNT, bool NODE32, bool LOCAL = false>
 __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
                                                   const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
-                                                  unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
+                                                  unsigned& n_int, unsigned& n_tri, unsigned& n_inst,
+                                                  const DMesh* lmesh = nullptr, uint8_t* __restrict__ side_out = nullptr) {
     constexpr unsigned WAVES = HPT_BLOCK / 64, QW = HPT_QUEUE_CAP / WAVES;
     static_assert((QW & (QW - 1)) == 0 && QW >= 128, "per-wave ring: power of two, room for 63 + 64 items");
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -471,9 +433,17 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             bool queued = false;
             uint2 item = make_uint2(0, 0);
             if (off0 + lane < cnt) {
-                Hit a;
-                queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, a, item, n_inst);
-                hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
+                if constexpr (LOCAL) {
+                    float tin;
+                    queued = box_hit(make_raybox(xyz(ray_o[i]), xyz(ray_d[i])), make_float3(lmesh->bmin[0], lmesh->bmin[1], lmesh->bmin[2]),
+                                     make_float3(lmesh->bmax[0], lmesh->bmax[1], lmesh->bmax[2]), HPT_INF, tin);
+                    item = make_uint2(i, 0u);
+                    hit[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); side_out[i] = 0;             // final unless a triangle is hit
+                } else {
+                    Hit a;
+                    queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, a, item, n_inst);
+                    hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
+                }
             }
             const unsigned long long mask = __ballot(queued);
             if (queued) queue[(qn + lane_prefix(mask)) & (QW - 1u)] = item;
@@ -493,7 +463,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                     slot = it.x; mpos = first_mpos = (int)it.y;
                     // 8-byte items keep the rings at 4 KB of LDS; the best analytic hit of phase 1 comes back from
                     // hit[] / hit_inst[] (L2-resident)
-                    ht = hit[slot].x; hinst = hit_inst[slot];
+                    if constexpr (!LOCAL) { ht = hit[slot].x; hinst = hit_inst[slot]; }
                     have = true; need_setup = true;
                 }
                 const unsigned nidle = (unsigned)__popcll(idle);
@@ -503,7 +473,17 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
         const bool exhausted = x >= total && qn == qhead;      // nothing left to pull, ever
         // ---- lanes whose mesh is finished (nothing of theirs is pending: the list was emptied below) merge its result
         //      and move on to the ray's next mesh instance
-        if (have && !need_setup && ref == SENTINEL) {
+        if (LOCAL && have && !need_setup && ref == SENTINEL) {
+            const unsigned long long key = *mybest;
+            if ((uint32_t)key != 0xffffffffu) {
+                const uint32_t sf = L.dsf[threadIdx.x];
+                const float t = (sf & 2u) ? -0.0f : __uint_as_float((uint32_t)(key >> 32));
+                hit[slot] = make_float4(t, L.du[threadIdx.x], L.dv[threadIdx.x], __int_as_float((int)(uint32_t)key - lmesh->tri_base));
+                side_out[slot] = (uint8_t)(sf & 1u);
+            }
+            have = false;
+        }
+        if (!LOCAL && have && !need_setup && ref == SENTINEL) {
             const unsigned long long key = *mybest;
             if ((uint32_t)key != 0xffffffffu) {
                 const float t = __uint_as_float((uint32_t)(key >> 32));
@@ -523,7 +503,14 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             need_setup = true;
         }
         // ---- setup: next mesh instance whose root box the ray enters, or retire the ray
-        if (need_setup) {
+        if (LOCAL && need_setup) {
+            lo = xyz(ray_o[slot]); ld = xyz(ray_d[slot]);
+            rb = make_raybox(lo, ld);
+            if (NODE32) rb = quant_slab(rb, lmesh->qbase, lmesh->qscale);
+            tm = HPT_INF; *mybest = HPT_KEY_NONE;
+            stk[0] = SENTINEL; sp = 1; ref = lmesh->root_ref;
+        }
+        if (!LOCAL && need_setup) {
             const f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
             for (;;) {
                 if (mpos >= sc.n_mesh_instances) { have = false; ref = SENTINEL; break; }      // hit[slot] is final
@@ -610,9 +597,6 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
 // << 26 | instance), one per lane.  The tester fetches the owner's WORLD ray through the LDS crossbar, walks the
 // instance's transform chain, runs the exact sphere / plane test and merges a hit into the owner's key with a 64-bit
 // LDS min: t bits << 32 | instance << 1 | side -- nearest hit, the earlier instance on equal t (scene.rs:196,251).
-#ifndef HPT_PARK
-#define HPT_PARK 12
-#endif
 #define HPT_ANALYTIC_BASE 0x60000000      // TLAS leaf refs: ~(HPT_INST_BASE + i) mesh instance, ~(HPT_ANALYTIC_BASE + i) sphere / plane
 template <bool COUNT>
 __device__ __forceinline__ void test_pending_analytic(const DScene& sc, const Lds& L, unsigned first, unsigned n, f3 o, f3 d, unsigned& n_inst) {
@@ -822,29 +806,13 @@ __device__ __forceinline__ T wave_sum(T v) {
 
 // ------------------------------------------------------------------------------------------------ k_trace_rays
 template <bool COUNT, bool NODE32>
-__global__ void __launch_bounds__(HPT_BLOCK)
-k_trace_rays(const float4* __restrict__ nodes, const float4* __restrict__ tris, int n_nodes, int stack_entries, DMesh mesh, long long n,
-             const float4* __restrict__ org, const float4* __restrict__ dir, float4* __restrict__ hit,
-             uint8_t* __restrict__ side_out, unsigned long long* stat) {
+__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(HPT_EXTEND_WAVES, HPT_EXTEND_WAVES)))
+k_trace_rays(DScene sc, int stack_entries, DMesh mesh, uint32_t n, const float4* __restrict__ org, const float4* __restrict__ dir,
+             float4* __restrict__ hit, uint8_t* __restrict__ side_out, unsigned long long* stat) {
     Lds L = lds_carve(stack_entries);
-    int* stk = L.stack + threadIdx.x;
-    unsigned n_int = 0, n_tri = 0;
-    for (long long base = (long long)blockIdx.x * HPT_BLOCK; base < n; base += (long long)gridDim.x * HPT_BLOCK) {
-        const long long i = base + threadIdx.x;
-        if (i < n) {
-            const f3 o = xyz(org[i]), d = xyz(dir[i]);
-            float tm = HPT_INF, bu = 0.0f, bv = 0.0f; int prim = -1, s = 0;
-            const RayBox rb = make_raybox(o, d);
-            float tin;
-            if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin))
-                traverse_mesh<COUNT, NODE32>(nodes, tris, mesh, o, d, HPT_INF, false, tm, prim, bu, bv, s, stk, n_int, n_tri);
-            float4 h;
-            if (prim >= 0) h = make_float4(tm, bu, bv, __int_as_float(prim - mesh.tri_base));
-            else h = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-            hit[i] = h;
-            side_out[i] = (uint8_t)s;
-        }
-    }
+    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = n; wv.cap = (n + HPT_BLOCK - 1) / HPT_BLOCK * HPT_BLOCK;
+    unsigned n_int = 0, n_tri = 0, n_inst = 0;
+    block_closest_hit<COUNT, NODE32, true>(sc, L, wv, org, dir, hit, nullptr, n_int, n_tri, n_inst, &mesh, side_out);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri);
         if ((threadIdx.x & 63) == 0) { atomicAdd(&stat[1], a); atomicAdd(&stat[2], b); }
@@ -1318,9 +1286,9 @@ static inline int grid_for(uint64_t n, int max_blocks) {
     return (int)b;
 }
 // stack entries the traversal kernels carve: the instance-list path never pushes a leaf (leaf children go to the pending
-// list), so it needs one entry less than traverse_mesh / the two-level path, whose count the host hands over
+// list), so it needs one entry less than the two-level path, whose count the host hands over
 static inline int carve_entries(int stack_entries, bool tlas) { return tlas ? stack_entries : (stack_entries > 2 ? stack_entries - 1 : stack_entries); }
-// dynamic LDS of the traversal kernels (see lds_carve / lds_carve_tlas): the stack alone (k_trace_rays), + rings and the
+// dynamic LDS of the traversal kernels (see lds_carve / lds_carve_tlas): the stack alone, + rings and the
 // deferred-triangle areas (instance-list path), or + key and pending list of deferred analytic instances (two-level path)
 enum { LDS_STACK = 0, LDS_LIST = 1, LDS_TLAS = 2 };
 static inline size_t trav_lds_bytes(int stack_entries, int mode) {
@@ -1354,10 +1322,19 @@ static int scene_lds_mode(int stack_entries, const DScene& sc) {
 }
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
                      const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat) {
-    const int grid = grid_for((uint64_t)n, max_blocks);
-    const size_t lds = trav_lds_bytes(mesh.stack_need, LDS_STACK);
+    // the same persistent closest-hit machinery as k_extend, fed with mesh-local rays (slots are 32-bit: 2^30 rays per launch)
+    const int se = carve_entries(mesh.stack_need, false);
+    const size_t lds = trav_lds_bytes(se, LDS_LIST);
     auto k = sc.node32 ? (count ? k_trace_rays<true, true> : k_trace_rays<false, true>) : (count ? k_trace_rays<true, false> : k_trace_rays<false, false>);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(HPT_BLOCK), lds, st, sc.nodes, sc.tris, sc.n_nodes, mesh.stack_need, mesh, n, org, dir, hit, side, stat);
+    int per_cu = resident_blocks(k, lds);
+    if (per_cu <= 0) per_cu = 4;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = max_blocks / 4;
+    for (long long base = 0; base < n; base += (1ll << 30)) {
+        const uint32_t m = (uint32_t)std::min<long long>(n - base, 1ll << 30);
+        const int grid = grid_for(m, std::max(1, cus * per_cu));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(HPT_BLOCK), lds, st, sc, se, mesh, m, org + base, dir + base, hit + base, side + base, stat);
+    }
 }
 void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
