@@ -30,8 +30,11 @@
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
 // lanes of a wave that must hold a leaf of one kind before its block runs (two-level kernel), see DESIGN.md
-#ifndef HPT_PARK
-#define HPT_PARK 12
+#ifndef HPT_PARK_TRI
+#define HPT_PARK_TRI 12
+#endif
+#ifndef HPT_PARK_INST
+#define HPT_PARK_INST 12
 #endif
 
 // ------------------------------------------------------------------------------------------------ vector helpers
@@ -697,7 +700,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
         const int keep_going_above = input_done ? 0 : 64 - L.refill;
         while (__popcll(__ballot(have && ref != SENTINEL)) > keep_going_above) {
             bool anaL = false, anaR = false; int l = 0, r = 0;
-            // Parking: a lane that holds a triangle or an instance leaf waits until HPT_PARK lanes of the wave hold the same
+            // Parking: a lane that holds a triangle or an instance leaf waits until HPT_PARK_TRI / HPT_PARK_INST lanes of the wave hold the same
             // kind (or no lane has a box step left), so the long, rarely needed blocks run in few steps with many lanes
             // instead of in every step with three or four.
             const bool at_leaf = have && ref < 0 && ref != SENTINEL;
@@ -706,8 +709,8 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
             bool go_tri = true, go_inst = true;
             if (park) {      // (scenes without mesh instances have nothing worth waiting for)
                 const bool no_box_step = __ballot(have && ref >= 0) == 0ull;
-                go_tri = no_box_step || __popcll(__ballot(at_tri)) >= HPT_PARK;
-                go_inst = no_box_step || __popcll(__ballot(at_inst)) >= HPT_PARK;
+                go_tri = no_box_step || __popcll(__ballot(at_tri)) >= HPT_PARK_TRI;
+                go_inst = no_box_step || __popcll(__ballot(at_inst)) >= HPT_PARK_INST;
             }
             if (have && ref >= 0) {
                 if (COUNT) n_int++;
