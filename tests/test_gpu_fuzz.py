@@ -48,7 +48,7 @@ def random_texture(rng, n_images):
     return scene_io.tex_color(col)
 
 
-def random_scene(seed, w=56, h=40):
+def random_scene(seed, w=56, h=40, mesh_tris=(20, 300), geom_p=(0.25, 0.3, 0.15, 0.3)):
     rng = np.random.default_rng(seed)
     d = scene_io.SceneDesc()
     for _ in range(2):
@@ -65,10 +65,12 @@ def random_scene(seed, w=56, h=40):
             mat.emission = rng.uniform(0.5, 4, 3).astype(F)
         d.materials.append(mat)
     for _ in range(int(rng.integers(1, 4))):
-        d.meshes.append(random_mesh(rng, int(rng.integers(20, 300))))
+        d.meshes.append(random_mesh(rng, int(rng.integers(mesh_tris[0], mesh_tris[1]))))
+
+    deep_p = None if tuple(geom_p) == (0.25, 0.3, 0.15, 0.3) else [g / sum(geom_p[1:]) for g in geom_p[1:]]   # (None: the scenes of the first test stay as they were)
 
     def add(parent, depth):
-        geom = int(rng.choice([0, 1, 2, 3], p=[0.25, 0.3, 0.15, 0.3])) if depth < 3 else int(rng.choice([1, 2, 3]))
+        geom = int(rng.choice([0, 1, 2, 3], p=list(geom_p))) if depth < 3 else int(rng.choice([1, 2, 3], p=deep_p))
         m, t = random_xform(rng, 3.0 if depth == 0 else 1.5)
         d.nodes.append(scene_io.Node(parent=parent, geom=geom, mesh=int(rng.integers(0, len(d.meshes))) if geom == 3 else -1,
                                      material=int(rng.integers(0, 6)) if geom else -1, m=m, t=t))
@@ -124,5 +126,38 @@ def test_random_scene(ctx, olib, seed, tlas, monkeypatch):
     rel = np.abs(got - ref["per_sample"]).max(axis=2) / (np.abs(ref["per_sample"]).max(axis=2) + 1e-3)
     assert (rel <= 1e-3).mean() >= 0.99, (rel <= 1e-3).mean()
     img = gsc.render(spp=6, max_depth=5, seed=seed)
+    assert float(np.sqrt(((img["rgb"] - ref["rgb"]) ** 2).mean()) / max(ref["rgb"].mean(), 1e-6)) <= 2e-2
+    gsc.close()
+
+
+@pytest.mark.parametrize("seed", [201, 203, 210])
+@pytest.mark.parametrize("tlas", [False, True])
+def test_tiny_meshes_and_mesh_heavy_scenes(ctx, olib, seed, tlas, monkeypatch):
+    """The corners of the closest-hit kernels the scenes above do not reach: meshes of 1..3 triangles (the root of the
+    tree is a leaf, or its children are), and scenes that are almost all mesh instances, where the two-level kernel tests
+    the few analytic instances in place (it defers them only when they are a quarter of the scene)."""
+    import hpt
+    d = random_scene(seed, mesh_tris=(1, 4), geom_p=(0.12, 0.02, 0.02, 0.84))
+    monkeypatch.setenv("HPT_TLAS_MIN", "2" if tlas else "1000000")
+    osc = ol.OracleScene(olib, d)
+    gsc = hpt.Scene(ctx, d)
+    info = gsc.info()
+    assert info.uses_tlas == int(tlas) and info.n_mesh_instances * 4 > info.n_instances * 3, (info.n_mesh_instances, info.n_instances)
+    o, dd = probe_rays(osc, d, 6000, seed)
+    g, r = gsc.intersect(o, dd), osc.intersect(o, dd)
+    for k in ("node", "prim", "t", "side", "pos", "normal"):
+        np.testing.assert_array_equal(g[k], r[k], err_msg=k)
+    # the triangles are small: aim a second batch at the points where the first one hit a triangle
+    on_tri = r["pos"][r["prim"] >= 0]
+    assert len(on_tri) >= 5
+    rng = np.random.default_rng(seed)
+    dirs = rng.normal(size=(len(on_tri) * 60, 3)); dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(F)
+    o2 = (np.repeat(on_tri, 60, axis=0) - dirs * rng.uniform(0.5, 6.0, (len(dirs), 1)).astype(F)).astype(F)
+    g, r = gsc.intersect(o2, dirs), osc.intersect(o2, dirs)
+    for k in ("node", "prim", "t", "side", "pos", "normal"):
+        np.testing.assert_array_equal(g[k], r[k], err_msg=k)
+    assert (r["prim"] >= 0).sum() > 100
+    ref = osc.render(spp=4, max_depth=4, seed=seed)
+    img = gsc.render(spp=4, max_depth=4, seed=seed)
     assert float(np.sqrt(((img["rgb"] - ref["rgb"]) ** 2).mean()) / max(ref["rgb"].mean(), 1e-6)) <= 2e-2
     gsc.close()
