@@ -728,7 +728,7 @@ static int extend_grid(const hpt_scene* s) {
 static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks) {
     hpt_context* ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(ps.counts, 0, (size_t)(HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNTS_PER_DEPTH * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(ps.counts, 0, (size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t), st));
     CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps); CHK(ev.end(st));
     const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
     const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
@@ -752,7 +752,7 @@ static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps) {
     const uint64_t max_paths = (uint64_t)shard_cap_for(n_paths) * HPT_SHARDS;   // slots of a sharded queue
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(s->w_q[a][k].ensure(max_paths * 16));
     CHK(s->w_hit.ensure(max_paths * 16)); CHK(s->w_hit_inst.ensure(max_paths * 4)); CHK(s->w_radiance.ensure(max_paths * 16));
-    CHK(s->w_counts.ensure((size_t)(HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNTS_PER_DEPTH * sizeof(uint32_t)));
+    CHK(s->w_counts.ensure((size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = s->w_q[a][0].as<float4>(); ps.q[a].ray_d = s->w_q[a][1].as<float4>(); ps.q[a].thr = s->w_q[a][2].as<float4>(); }
     ps.hit = s->w_hit.as<float4>(); ps.hit_inst = s->w_hit_inst.as<uint32_t>(); ps.radiance = s->w_radiance.as<float4>();

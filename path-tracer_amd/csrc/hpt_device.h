@@ -34,6 +34,13 @@
 #define HPT_COUNT_STRIDE 32      // uint32 slots between two append counters: one counter per 128-B line (L2 atomics to one line serialise)
 #endif
 #define HPT_COUNTS_PER_DEPTH (HPT_SHARDS * HPT_COUNT_STRIDE)
+// DPass.counts holds HPT_MAX_DEPTH_LIMIT + 2 blocks of append counters, then one work counter per depth (k_extend hands
+// its input out in batches of HPT_PIECE_BATCH 64-ray pieces), HPT_COUNT_STRIDE apart like the others
+#define HPT_COUNTS_TOTAL ((HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNTS_PER_DEPTH + (HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNT_STRIDE)
+#define HPT_WORK_COUNTER(depth) ((HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNTS_PER_DEPTH + (depth) * HPT_COUNT_STRIDE)
+#ifndef HPT_PIECE_BATCH
+#define HPT_PIECE_BATCH 8
+#endif
 #ifndef HPT_QUEUE_CAP
 #define HPT_QUEUE_CAP 512
 #endif

@@ -283,7 +283,7 @@ __device__ __forceinline__ Lds lds_carve_tlas(int stack_entries, bool defer) {
 // (w % shards); a persistent workgroup takes w = blockIdx.x, + gridDim.x, ...  Producers append to the segment they
 // consume from, so each of the `shards` append counters sees 1/shards of the atomics (one counter for the whole queue
 // serialises at ~11 ns per returning atomic: 130 k wave-appends per 8 M-path launch = 1.4 ms, the whole k_shade time).
-struct WorkView { const uint32_t* counts; uint32_t cap; uint32_t shards; uint32_t n_linear; };
+struct WorkView { const uint32_t* counts; uint32_t cap; uint32_t shards; uint32_t n_linear; uint32_t* work; };   // work: see PieceFeed
 __device__ __forceinline__ uint32_t work_items(const WorkView& wv) { return wv.shards * (wv.cap / HPT_BLOCK); }
 __device__ __forceinline__ bool work_slot(const WorkView& wv, uint32_t w, uint32_t& slot) {
     const uint32_t s = w % wv.shards, k = w / wv.shards;
@@ -305,6 +305,38 @@ __device__ __forceinline__ uint32_t input_pieces(const WorkView& wv) {
     maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
     return wv.shards * ((maxcnt + HPT_BLOCK - 1) / HPT_BLOCK) * (HPT_BLOCK / 64);
 }
+
+// Which 64-slot piece a wave takes next.  DYNAMIC (k_extend: a work counter zeroed by the pass): pieces are handed out
+// HPT_PIECE_BATCH at a time with one atomic per batch -- ray costs differ, and with a static split the waves of a
+// launch finish at different times and leave their SIMD slots empty.  Static (the test entries): piece x = global
+// wave, + number of waves, ...
+template <bool DYNAMIC> struct PieceFeed;
+template <> struct PieceFeed<true> {
+    uint32_t xb, xe, total; uint32_t* work; bool none_left;
+    __device__ __forceinline__ PieceFeed(const WorkView& wv) : xb(0u), xe(0u), total(input_pieces(wv)), work(wv.work), none_left(false) {}
+    __device__ __forceinline__ bool done() const { return none_left; }
+    __device__ __forceinline__ bool next(uint32_t& x) {      // wave-uniform
+        if (xb >= xe) {
+            uint32_t v = 0;
+            if ((threadIdx.x & 63u) == 0u) v = atomicAdd(work, (uint32_t)HPT_PIECE_BATCH);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v >= total) { none_left = true; return false; }
+            xb = v; xe = min(v + (uint32_t)HPT_PIECE_BATCH, total);
+        }
+        x = xb++;
+        return true;
+    }
+};
+template <> struct PieceFeed<false> {
+    uint32_t xb, total, xstep;
+    __device__ __forceinline__ PieceFeed(const WorkView& wv) : xb(blockIdx.x * (HPT_BLOCK / 64) + (threadIdx.x >> 6)), total(input_pieces(wv)), xstep(gridDim.x * (HPT_BLOCK / 64)) {}
+    __device__ __forceinline__ bool done() const { return xb >= total; }
+    __device__ __forceinline__ bool next(uint32_t& x) {
+        if (xb >= total) return false;
+        x = xb; xb += xstep;
+        return true;
+    }
+};
 
 // phase 1 for one ray: analytic instances + first mesh box entered.  Returns true when the ray must be queued.
 template <bool COUNT>
@@ -398,7 +430,8 @@ __device__ __forceinline__ void test_pending(const Lds& L, const float4* __restr
 // Rays are identified by their slot i; results go to hit[i] / hit_inst[i] exactly once per ray.
 // LOCAL (the Mesh::intersect test entry, k_trace_rays): rays are given in the space of ONE mesh, `lmesh`; phase 1 is its
 // root-box test alone, and the result is hit[i] = (t, u, v, triangle index inside the mesh | -1), side_out[i].
-template <bool COUNT, bool NODE32, bool LOCAL = false>
+// DYNAMIC: the launch has a work counter (wv.work, zeroed beforehand) and input pieces are handed out through it.
+template <bool COUNT, bool NODE32, bool LOCAL = false, bool DYNAMIC = false>
 __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
                                                   const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                   unsigned& n_int, unsigned& n_tri, unsigned& n_inst,
@@ -413,9 +446,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     const int SENTINEL = (int)0x80000000;
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
-    const uint32_t total = input_pieces(wv);
-    const uint32_t xstep = gridDim.x * WAVES;
-    uint32_t x = blockIdx.x * WAVES + wave;
+    PieceFeed<DYNAMIC> feed(wv);
     unsigned qn = 0, qhead = 0, pend = 0;                // wave-uniform: ring counters (monotonic), pending-list fill
     bool have = false;
     uint32_t slot = 0; int mpos = 0, first_mpos = 0;
@@ -425,9 +456,10 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     float tm = HPT_INF; int ref = SENTINEL, sp = 1, inst_idx = 0;
     for (;;) {
         // ---- phase 1 until a full wave of rays is queued (or the input ends)
-        while (x < total && qn - qhead < 64u) {
+        while (!feed.done() && qn - qhead < 64u) {
+            uint32_t x;
+            if (!feed.next(x)) break;
             const uint32_t w = x / WAVES, sub = x % WAVES;
-            x += xstep;
             const uint32_t seg = w % wv.shards, k = w / wv.shards;
             const uint32_t cnt = wv.counts ? wv.counts[seg * HPT_COUNT_STRIDE] : wv.n_linear;
             const uint32_t off0 = k * HPT_BLOCK + sub * 64u;
@@ -473,7 +505,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 qhead += nidle < avail ? nidle : avail;
             }
         }
-        const bool exhausted = x >= total && qn == qhead;      // nothing left to pull, ever
+        const bool exhausted = feed.done() && qn == qhead;      // nothing left to pull, ever
         // ---- lanes whose mesh is finished (nothing of theirs is pending: the list was emptied below) merge its result
         //      and move on to the ray's next mesh instance
         if (LOCAL && have && !need_setup && ref == SENTINEL) {
@@ -629,7 +661,7 @@ __device__ __forceinline__ void test_pending_analytic(const DScene& sc, const Ld
 // Every wave is a persistent worker of its own (no workgroup barrier): it walks the 64-slot pieces x = global wave,
 // + number of waves, ... of the input (piece x = quarter x % 4 of chunk x / 4) and hands their rays to lanes as they
 // fall idle, so under-filled steps only occur at the very end of the launch.
-template <bool COUNT, bool NODE32, bool DEFER>
+template <bool COUNT, bool NODE32, bool DEFER, bool DYNAMIC = false>
 __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
                                                        const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                        unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
@@ -639,9 +671,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
     const int SENTINEL = (int)0x80000000;
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
-    const uint32_t total = input_pieces(wv);
-    const uint32_t xstep = gridDim.x * WAVES;
-    uint32_t x = blockIdx.x * WAVES + wave;
+    PieceFeed<DYNAMIC> feed(wv);
     uint32_t piece_slot = 0, piece_n = 0, piece_pos = 0;      // wave-uniform: the piece rays are being handed out from
     const bool park = sc.n_mesh_instances > 0;
     unsigned long long* mybest = L.best + threadIdx.x;        // best analytic hit of the lane's ray: t bits << 32 | instance << 1 | side
@@ -672,9 +702,9 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
             if (idle == 0ull) break;
             if (piece_pos >= piece_n) {
                 bool found = false;
-                while (x < total) {
+                uint32_t x;
+                while (feed.next(x)) {
                     const uint32_t w = x / WAVES, sub = x % WAVES;
-                    x += xstep;
                     const uint32_t seg = w % wv.shards, k = w / wv.shards;
                     const uint32_t cnt = wv.counts ? wv.counts[seg * HPT_COUNT_STRIDE] : wv.n_linear;
                     const uint32_t off0 = k * HPT_BLOCK + sub * 64u;
@@ -813,7 +843,7 @@ __global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 k_trace_rays(DScene sc, int stack_entries, DMesh mesh, uint32_t n, const float4* __restrict__ org, const float4* __restrict__ dir,
              float4* __restrict__ hit, uint8_t* __restrict__ side_out, unsigned long long* stat) {
     Lds L = lds_carve(stack_entries);
-    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = n; wv.cap = (n + HPT_BLOCK - 1) / HPT_BLOCK * HPT_BLOCK;
+    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = n; wv.cap = (n + HPT_BLOCK - 1) / HPT_BLOCK * HPT_BLOCK; wv.work = nullptr;
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
     block_closest_hit<COUNT, NODE32, true>(sc, L, wv, org, dir, hit, nullptr, n_int, n_tri, n_inst, &mesh, side_out);
     if (COUNT) {
@@ -873,9 +903,12 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     L.refill = refill;
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
+    wv.work = ps.counts + HPT_WORK_COUNTER(depth);
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
-    if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
-    else block_closest_hit<COUNT, NODE32>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    // (the instance-list kernel keeps the static split: its rays are cheap, and handing pieces out through the counter
+    //  measured +16 % at 8 pieces per atomic, more for smaller -- contention -- and larger -- imbalance -- batches)
+    else block_closest_hit<COUNT, NODE32, false, false>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
                            c = wave_sum<unsigned long long>(n_inst);
@@ -1026,7 +1059,7 @@ k_scene_closest(DScene sc, long long n, const float4* __restrict__ org, const fl
                 float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, int stack_entries, int defer) {
     Lds L = sc.use_tlas ? lds_carve_tlas(stack_entries, defer != 0) : lds_carve(stack_entries);
     unsigned c0 = 0, c1 = 0, c2 = 0;
-    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n;
+    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n; wv.work = nullptr;
     wv.cap = (uint32_t)((n + HPT_BLOCK - 1) / HPT_BLOCK) * HPT_BLOCK;
     if (sc.use_tlas) {
         if (defer) { if (sc.node32) block_closest_hit_tlas<false, true, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit_tlas<false, false, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
@@ -1081,7 +1114,7 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
     }
     const DQueue& qi = ps.q[depth & 1];
     const DQueue& qo = ps.q[(depth + 1) & 1];
-    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
+    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.work = nullptr;
     uint32_t* counts_out = ps.counts + (size_t)(depth + 1) * HPT_COUNTS_PER_DEPTH;
     const int lane = threadIdx.x & 63;
     const uint32_t total = work_items(wv);
