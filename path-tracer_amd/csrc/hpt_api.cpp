@@ -729,6 +729,7 @@ static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool c
     hpt_context* ctx = s->ctx;
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemsetAsync(ps.counts, 0, (size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(ps.radiance, 0, (size_t)ps.n_slots * ps.S * sizeof(float4), st));
     CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps); CHK(ev.end(st));
     const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
     const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
@@ -808,7 +809,7 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
             HIPCHK(hipMemcpy(rad.data(), ps.radiance, rad.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (uint64_t px = 0; px < npix; ++px)
                 for (int k = 0; k < cur; ++k)
-                    for (int c = 0; c < 3; ++c) per_sample_host[(px * (uint64_t)p->spp + (uint64_t)(done + k)) * 3 + c] = rad[(px * (uint64_t)cur + (uint64_t)k) * 4 + c];
+                    for (int c = 0; c < 3; ++c) per_sample_host[(px * (uint64_t)p->spp + (uint64_t)(done + k)) * 3 + c] = rad[((uint64_t)k * npix + px) * 4 + c];      // radiance is sample-major
         }
     }
     if (stats) { stats->passes += passes; stats->samples += npix * (uint64_t)p->spp; }

@@ -117,7 +117,7 @@ struct DScene {
 // wavefront queues (SoA).  A path keeps its identity (path id = pixel_slot * S + s) in ray_d.w.
 struct DQueue {
     float4* ray_o;   // (origin.xyz, roulette weight)                       scene.rs:130 `weight`
-    float4* ray_d;   // (dir.xyz, as_float(path id))
+    float4* ray_d;   // (dir.xyz, as_float(index of the path's radiance record))
     float4* thr;     // (throughput.rgb, 0): product of n.dot(new_dir)*albedo/p over the bounces so far
 };
 
@@ -125,7 +125,7 @@ struct DPass {
     DQueue q[2];
     float4* hit;         // (t, u, v, as_float(global tri or -1))
     uint32_t* hit_inst;  // instance | side<<31, HPT_MISS_INST on miss
-    float4* radiance;    // per path id: (L.rgb, 0)
+    float4* radiance;    // (L.rgb, 0) of sample s of slot i at [s * n_slots + i] (k_resolve reads it coalesced); zeroed by the pass
     uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2][HPT_SHARDS] live paths per depth and queue segment, HPT_COUNT_STRIDE apart
     uint32_t shard_cap;  // slots per segment (multiple of HPT_BLOCK); a queue holds HPT_SHARDS * shard_cap slots
     const float2* halton;        // [S] (halton(i,2), halton(i,3)) of this pass's samples

@@ -853,7 +853,7 @@ k_trace_rays(DScene sc, int stack_entries, DMesh mesh, uint32_t n, const float4*
 }
 
 // ------------------------------------------------------------------------------------------------ k_raygen
-// main.rs:65-85.  path id = slot * S + s; slot -> pixel through pixel_list in adaptive passes.
+// main.rs:65-85.  path = slot * S + s (queue order); slot -> pixel through pixel_list in adaptive passes.
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_raygen(DScene sc, DPass ps) {
     const DCamera& c = sc.cam;
@@ -877,9 +877,8 @@ k_raygen(DScene sc, DPass ps) {
         const uint32_t chunk = path / HPT_BLOCK, seg = chunk % HPT_SHARDS, k = chunk / HPT_SHARDS;
         const uint32_t q = seg * ps.shard_cap + k * HPT_BLOCK + (path % HPT_BLOCK);
         ps.q[0].ray_o[q] = make_float4(eye.x, eye.y, eye.z, 1.0f);
-        ps.q[0].ray_d[q] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(path));
+        ps.q[0].ray_d[q] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(s * ps.n_slots + slot));   // its radiance record
         ps.q[0].thr[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel | (s << 26)));   // pixel < 2^26, s < 64
-        ps.radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0 && threadIdx.x < HPT_SHARDS) {
         // live entries of segment s at depth 0: its full chunks + (maybe) the globally last, partial chunk
@@ -1240,9 +1239,9 @@ k_resolve(DPass ps, float* __restrict__ accum, float* __restrict__ minmax) {
         float r = accum[3 * (size_t)pixel], g = accum[3 * (size_t)pixel + 1], b = accum[3 * (size_t)pixel + 2];
         float mn[3], mx[3];
         if (minmax) for (int c = 0; c < 3; ++c) { mn[c] = minmax[6 * (size_t)pixel + c]; mx[c] = minmax[6 * (size_t)pixel + 3 + c]; }
-        const float4* L = ps.radiance + (size_t)slot * ps.S;
+        const float4* L = ps.radiance + slot;
         for (uint32_t s = 0; s < ps.S; ++s) {
-            const float4 v = L[s];
+            const float4 v = L[(size_t)s * ps.n_slots];
             r += v.x; g += v.y; b += v.z;
             if (minmax) {
                 if (v.x < mn[0]) mn[0] = v.x;
@@ -1259,15 +1258,14 @@ k_resolve(DPass ps, float* __restrict__ accum, float* __restrict__ minmax) {
 }
 
 // live-count bookkeeping at the end of a pass: rays traced = sum of the per-depth queue lengths
-__global__ void k_finish_pass(DPass ps) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long tot = 0;
-        unsigned long long prim = 0;
-        for (int d = 0; d <= ps.max_depth; ++d)
-            for (int s = 0; s < HPT_SHARDS; ++s) { tot += ps.counts[d * HPT_COUNTS_PER_DEPTH + s * HPT_COUNT_STRIDE]; if (d == 0) prim += ps.counts[s * HPT_COUNT_STRIDE]; }
-        ps.stat[0] += tot;
-        ps.stat[4] += prim;
+__global__ void k_finish_pass(DPass ps) {      // one wave: lane = queue segment (+64, ...), summed over the depths
+    unsigned long long tot = 0, prim = 0;
+    for (unsigned s = threadIdx.x; s < HPT_SHARDS; s += 64u) {
+        for (int d = 0; d <= ps.max_depth; ++d) tot += ps.counts[d * HPT_COUNTS_PER_DEPTH + s * HPT_COUNT_STRIDE];
+        prim += ps.counts[s * HPT_COUNT_STRIDE];
     }
+    tot = wave_sum<unsigned long long>(tot); prim = wave_sum<unsigned long long>(prim);
+    if (threadIdx.x == 0) { ps.stat[0] += tot; ps.stat[4] += prim; }
 }
 
 // main.rs:101 decision per pixel after a round: writes the still-active pixel list for the next round
