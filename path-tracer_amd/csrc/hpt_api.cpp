@@ -499,6 +499,8 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         conv_texture(m.diffuse, mats[i].diffuse); conv_texture(m.reflection, mats[i].reflection); conv_texture(m.refraction, mats[i].refraction);
         for (int k = 0; k < 3; ++k) mats[i].emission[k] = m.emission[k];
         mats[i].refl_gloss = m.reflection_glossiness; mats[i].refr_gloss = m.refraction_glossiness; mats[i].ior = m.refraction_index;
+        mats[i].cos_refl_gloss = cosf(m.reflection_glossiness); mats[i].cos_refr_gloss = cosf(m.refraction_glossiness);
+        { volatile float n1 = 1.0f, n2 = m.refraction_index; volatile float q = (n1 - n2) / (n1 + n2); mats[i].r0 = q * q; }   // same value from either side
     }
     std::vector<DImage> imgs(s->images.size()); std::vector<uint8_t> pool;
     for (size_t i = 0; i < imgs.size(); ++i) {

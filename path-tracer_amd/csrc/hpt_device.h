@@ -83,6 +83,9 @@ struct DMaterial {
     DTexture diffuse, reflection, refraction;
     float emission[3];
     float refl_gloss, refr_gloss, ior;
+    // per-material constants of the bounce, computed once at commit with the host's IEEE arithmetic / libm (the values
+    // scene.rs:150,408 recompute per hit): cos of the two glossiness cone angles, Schlick r0 = ((1 - ior) / (1 + ior))^2
+    float cos_refl_gloss, cos_refr_gloss, r0;
 };
 struct DImage {
     uint64_t offset;   // byte offset into the image pool

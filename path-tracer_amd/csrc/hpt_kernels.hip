@@ -1158,7 +1158,7 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                 const f3 normal = w.side ? w.normal : neg3(w.normal);
                 float n1, n2;
                 if (w.side) { n1 = 1.0f; n2 = mat.ior; } else { n1 = mat.ior; n2 = 1.0f; }
-                float r0 = (n1 - n2) / (n1 + n2); r0 = r0 * r0;
+                const float r0 = mat.r0;      // ((n1 - n2) / (n1 + n2))^2: the same value from either side
                 float c1 = 1.0f - dot3(normal, neg3(d));
                 float c2 = c1 * c1;
                 const float ar = r0 + (1.0f - r0) * (c2 * c2 * c1);
@@ -1183,13 +1183,13 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                         if (rnd < p_diffuse) {
                             albedo = diffuse; p = p_diffuse;                       // scene.rs:413-429: hemisphere, z_min = 0
                         } else if (rnd < p_diffuse + p_reflection) {
-                            const float z_min = cosf(mat.refl_gloss);
+                            const float z_min = mat.cos_refl_gloss;
                             axis = reflect_ray(neg3(d), normal); z = z_min + ra * (1.0f - z_min);
                             albedo = reflection; p = p_reflection;
                         } else if (rnd < p_diffuse + p_reflection + p_refraction) {
                             f3 rd;
                             if (!refract_ray(neg3(d), normal, n1, n2, rd)) rd = reflect_ray(neg3(d), normal);
-                            const float z_min = cosf(mat.refr_gloss);
+                            const float z_min = mat.cos_refr_gloss;
                             axis = rd; z = z_min + ra * (1.0f - z_min);
                             albedo = refraction; p = p_refraction;
                         } else picked = false;
