@@ -205,37 +205,39 @@ __device__ __forceinline__ Slab quant_slab(const Slab& s, const float* qbase, co
 }
 // slab test (bvh.rs:225-281 semantics + the two culls the reference lacks: box behind the origin, box beyond bound):
 // lo* / hi* = the smaller / larger coordinate of the box per axis (float, or the 16-bit grid value as float)
-__device__ __forceinline__ bool slab_hit(const Slab& s, float lox, float hix, float loy, float hiy, float loz, float hiz, float bound, float& tin) {
+// bound_s: the closest-t bound times HPT_SLACK (scaled by the caller: the inner loops keep it in a register)
+#define HPT_SLACK 1.000001f
+__device__ __forceinline__ bool slab_hit(const Slab& s, float lox, float hix, float loy, float hiy, float loz, float hiz, float bound_s, float& tin) {
     const bool px = s.ax > 0.0f, py = s.ay > 0.0f, pz = s.az > 0.0f;   // (quantised slabs keep the sign: qscale > 0)
     const float ex = __builtin_fmaf(px ? lox : hix, s.ax, s.blx), ey = __builtin_fmaf(py ? loy : hiy, s.ay, s.bly), ez = __builtin_fmaf(pz ? loz : hiz, s.az, s.blz);
     const float xx = __builtin_fmaf(px ? hix : lox, s.ax, s.bhx), xy = __builtin_fmaf(py ? hiy : loy, s.ay, s.bhy), xz = __builtin_fmaf(pz ? hiz : loz, s.az, s.bhz);
     tin = fmaxf(fmaxf(ex, ey), ez);
-    const float tout = fminf(fminf(xx, xy), xz) * 1.000001f;
-    return (tin <= tout) && (tout >= 0.0f) && (tin <= bound * 1.000001f);
+    const float tout = fminf(fminf(xx, xy), xz) * HPT_SLACK;
+    return (tin <= tout) && (tout >= 0.0f) && (tin <= bound_s);
 }
-__device__ __forceinline__ bool box_hit(const Slab& rb, float3 bmin, float3 bmax, float bound, float& tin) {
-    return slab_hit(rb, bmin.x, bmax.x, bmin.y, bmax.y, bmin.z, bmax.z, bound, tin);
+__device__ __forceinline__ bool box_hit(const Slab& rb, float3 bmin, float3 bmax, float bound_s, float& tin) {
+    return slab_hit(rb, bmin.x, bmax.x, bmin.y, bmax.y, bmin.z, bmax.z, bound_s, tin);
 }
 // 16-bit box word = min | max << 16 along one axis
-__device__ __forceinline__ bool qbox_hit(const Slab& qs, uint32_t wx, uint32_t wy, uint32_t wz, float bound, float& tin) {
-    return slab_hit(qs, (float)(wx & 0xffffu), (float)(wx >> 16), (float)(wy & 0xffffu), (float)(wy >> 16), (float)(wz & 0xffffu), (float)(wz >> 16), bound, tin);
+__device__ __forceinline__ bool qbox_hit(const Slab& qs, uint32_t wx, uint32_t wy, uint32_t wz, float bound_s, float& tin) {
+    return slab_hit(qs, (float)(wx & 0xffffu), (float)(wx >> 16), (float)(wy & 0xffffu), (float)(wy >> 16), (float)(wz & 0xffffu), (float)(wz >> 16), bound_s, tin);
 }
 // One interior node: fetch the record (Node64: 4 quads, Node32: 2) and test both child boxes against the lane's slab
 // (`ns` must be the quantised slab of the tree's grid for Node32).
 template <bool NODE32>
-__device__ __forceinline__ void test_children(const float4* __restrict__ nodes, int ref, const Slab& ns, float bound,
+__device__ __forceinline__ void test_children(const float4* __restrict__ nodes, int ref, const Slab& ns, float bound_s,
                                               bool& hitL, bool& hitR, float& tinL, float& tinR, int& l, int& r) {
     if constexpr (NODE32) {
         const uint4* nq = (const uint4*)nodes + (uint32_t)ref * 2u;
         const uint4 q0 = nq[0], q1 = nq[1];
-        hitL = qbox_hit(ns, q0.x, q0.y, q0.z, bound, tinL);
-        hitR = qbox_hit(ns, q1.x, q1.y, q1.z, bound, tinR);
+        hitL = qbox_hit(ns, q0.x, q0.y, q0.z, bound_s, tinL);
+        hitR = qbox_hit(ns, q1.x, q1.y, q1.z, bound_s, tinR);
         l = (int)q0.w; r = (int)q1.w;
     } else {
         const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
         const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
-        hitL = box_hit(ns, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound, tinL);
-        hitR = box_hit(ns, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound, tinR);
+        hitL = box_hit(ns, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound_s, tinL);
+        hitR = box_hit(ns, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound_s, tinR);
         l = __float_as_int(q0.w); r = __float_as_int(q1.w);
     }
 }
@@ -453,7 +455,8 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     f3 lo = mk3(0, 0, 0), ld = mk3(0, 0, 1);
     float ht = HPT_INF; uint32_t hinst = HPT_MISS_INST;      // scene-level nearest so far of the lane's ray (t, instance | side)
     RayBox rb = make_raybox(lo, ld);
-    float tm = HPT_INF; int ref = SENTINEL, sp = 1, inst_idx = 0;
+    float bound_s = HPT_INF;      // min(nearest triangle of this mesh as of the last batch, scene-level nearest) * HPT_SLACK
+    int ref = SENTINEL, sp = 1, inst_idx = 0;
     for (;;) {
         // ---- phase 1 until a full wave of rays is queued (or the input ends)
         while (!feed.done() && qn - qhead < 64u) {
@@ -542,7 +545,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             lo = xyz(ray_o[slot]); ld = xyz(ray_d[slot]);
             rb = make_raybox(lo, ld);
             if (NODE32) rb = quant_slab(rb, lmesh->qbase, lmesh->qscale);
-            tm = HPT_INF; *mybest = HPT_KEY_NONE;
+            bound_s = HPT_INF; *mybest = HPT_KEY_NONE;
             stk[0] = SENTINEL; sp = 1; ref = lmesh->root_ref;
         }
         if (!LOCAL && need_setup) {
@@ -562,9 +565,9 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 const DMesh* mesh = sc.meshes + in->mesh;
                 rb = make_raybox(lo, ld);
                 float tin;
-                if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), ht, tin)) {
+                if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), ht * HPT_SLACK, tin)) {
                     if (NODE32) rb = quant_slab(rb, mesh->qbase, mesh->qscale);   // from here on rb addresses the tree's 16-bit grid
-                    tm = HPT_INF; *mybest = HPT_KEY_NONE;
+                    bound_s = ht * HPT_SLACK; *mybest = HPT_KEY_NONE;
                     stk[0] = SENTINEL; sp = 1; ref = mesh->root_ref;
                     break;
                 }
@@ -582,7 +585,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             if (ref >= 0) {
                 if (COUNT) n_int++;
                 bool hitL, hitR; float tinL, tinR;
-                test_children<NODE32>(nodes, ref, rb, fminf(tm, ht), hitL, hitR, tinL, tinR, l, r);
+                test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r);
                 leafL = hitL && l < 0; leafR = hitR && r < 0;
                 const bool intL = hitL && l >= 0, intR = hitR && r >= 0;
                 if (intL && intR) {
@@ -605,7 +608,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 pend += (unsigned)__popcll(mR);
                 if (pend >= 64u) {
                     do { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); } while (pend >= 64u);
-                    tm = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
+                    bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
                 }
             }
         }
@@ -615,7 +618,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             pend -= n;
             test_pending<COUNT>(L, tris, pend, n, lo, ld, n_tri);
         }
-        tm = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
+        bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
     }
 }
 
@@ -745,7 +748,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
             if (have && ref >= 0) {
                 if (COUNT) n_int++;
                 bool hitL, hitR; float tinL, tinR;
-                test_children<NODE32>(nodes, ref, rb, fminf(h.t, ta), hitL, hitR, tinL, tinR, l, r);
+                test_children<NODE32>(nodes, ref, rb, fminf(h.t, ta) * HPT_SLACK, hitL, hitR, tinL, tinR, l, r);
                 // a child that is an analytic instance (sphere / plane) is not walked into: it goes to the pending list
                 anaL = DEFER && hitL && l < 0 && (uint32_t)~l >= (uint32_t)HPT_ANALYTIC_BASE;
                 anaR = DEFER && hitR && r < 0 && (uint32_t)~r >= (uint32_t)HPT_ANALYTIC_BASE;
@@ -792,7 +795,7 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
                         const DMesh* mesh = sc.meshes + in->mesh;
                         const RayBox lrb = make_raybox(lo, ld);
                         float tin;
-                        if (box_hit(lrb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), fminf(h.t, ta), tin)) {
+                        if (box_hit(lrb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), fminf(h.t, ta) * HPT_SLACK, tin)) {
                             co = lo; cd = ld; cur_inst = i;
                             rb = NODE32 ? quant_slab(lrb, mesh->qbase, mesh->qscale) : lrb;
                             stk[sp * HPT_BLOCK] = HPT_REF_RESTORE;
