@@ -898,7 +898,9 @@ k_raygen(DScene sc, DPass ps) {
 
 // ------------------------------------------------------------------------------------------------ k_extend
 // DEFER (two-level only): analytic instances go through the pending list (the launch then carves key + list in LDS)
-template <bool COUNT, bool TLAS, bool NODE32, bool DEFER>
+// DYN: input pieces come through the work counter of this depth (always for the two-level path; for the instance-list
+// path when the rays are expensive -- big trees -- see extend_kernel)
+template <bool COUNT, bool TLAS, bool NODE32, bool DEFER, bool DYN>
 __global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : HPT_EXTEND_WAVES, TLAS ? 4 : HPT_EXTEND_WAVES)))
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     Lds L = TLAS ? lds_carve_tlas(stack_entries, DEFER) : lds_carve(stack_entries);
@@ -908,9 +910,7 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     wv.work = ps.counts + HPT_WORK_COUNTER(depth);
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
     if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
-    // (the instance-list kernel keeps the static split: its rays are cheap, and handing pieces out through the counter
-    //  measured +16 % at 8 pieces per atomic, more for smaller -- contention -- and larger -- imbalance -- batches)
-    else block_closest_hit<COUNT, NODE32, false, false>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    else block_closest_hit<COUNT, NODE32, false, DYN>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
                            c = wave_sum<unsigned long long>(n_inst);
@@ -1341,11 +1341,17 @@ static int resident_blocks(K k, size_t lds) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, HPT_BLOCK, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
+// The instance-list kernel takes its input through the work counter when the scene's trees are big (rays cost tens of
+// steps: 1 M-triangle soup -4 %), and keeps the static stride when they are small (teapot: the counter costs +16 %).
+static inline bool extend_dynamic(const DScene& sc) { return sc.n_nodes >= 65536; }
 template <bool COUNT>
 static auto extend_kernel(const DScene& sc, bool defer) -> void (*)(DScene, DPass, int, int, int) {
-    if (!sc.use_tlas) return sc.node32 ? k_extend<COUNT, false, true, false> : k_extend<COUNT, false, false, false>;
-    if (defer) return sc.node32 ? k_extend<COUNT, true, true, true> : k_extend<COUNT, true, false, true>;
-    return sc.node32 ? k_extend<COUNT, true, true, false> : k_extend<COUNT, true, false, false>;
+    if (!sc.use_tlas) {
+        if (extend_dynamic(sc)) return sc.node32 ? k_extend<COUNT, false, true, false, true> : k_extend<COUNT, false, false, false, true>;
+        return sc.node32 ? k_extend<COUNT, false, true, false, false> : k_extend<COUNT, false, false, false, false>;
+    }
+    if (defer) return sc.node32 ? k_extend<COUNT, true, true, true, true> : k_extend<COUNT, true, false, true, true>;
+    return sc.node32 ? k_extend<COUNT, true, true, false, true> : k_extend<COUNT, true, false, false, true>;
 }
 static int extend_resident(const DScene& sc, bool defer, size_t lds) { return resident_blocks(extend_kernel<false>(sc, defer), lds); }
 // LDS layout a scene's closest-hit kernels run with.  Two-level scenes defer their analytic instances (key + pending

@@ -49,8 +49,9 @@ def check_scene(ctx, olib, desc, n_rays, spp, depth, host_bvh=None, img_tol=2e-3
     return (r["node"] >= 0).mean()
 
 
-def test_config3_soup(ctx, olib):
-    desc = scenes.soup(20000)
+@pytest.mark.parametrize("ntri", [20000, 70000])      # from 65 536 nodes on k_extend takes its input through the work counter
+def test_config3_soup(ctx, olib, ntri):
+    desc = scenes.soup(ntri)
     hit_rate = check_scene(ctx, olib, desc, 20000, spp=4, depth=8)
     assert hit_rate > 0.3
 
