@@ -48,6 +48,21 @@ def recorded_traffic(kernel):
     return best
 
 
+def recorded_valu(kernel):
+    """VALU-busy fraction of `kernel` from the committed SQ counter pass (profiles/*_pmc_valu.json, written by
+    scripts/make_valu_json.py from a `rocprofv3 --pmc` run of the same frame at 8 M-path passes).  None if absent."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json"))):
+        try:
+            rec = json.load(open(f))
+            best = {"frac": float(rec[kernel]["valu_busy_frac"]), "valu_wave_insts_per_launch": float(rec[kernel]["valu_wave_insts_per_launch"]),
+                    "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return best
+
+
 def parity_ray_rates(scene, desc, n_gpu=10_000_000, n_cpu=1_000_000):
     """SURVEY 8d.6 beside the frame metric: closest-hit rate of k_trace_rays on the 10 M seeded parity rays (device
     buffers, HIP-event kernel time) and of the oracle's Mesh::intersect restatement on the first 1 M of them (host cores),
@@ -226,7 +241,9 @@ def main():
                          "scene_bytes_in_hbm": int(info.device_bytes),
                          "bvh_fetch_frac": round(bvh_bytes_per_ray * rays_local / ext_s_local / HBM_PEAK, 4),
                          "avg_launch_ms": round(ext_s_local / max(ext_launches, 1) * 1e3, 4), "launches": int(ext_launches),
-                         "extend_share_of_step": round(ext_s_local / (elapsed), 3), "shade_share_of_step": round(shade_s_local / elapsed, 3)},
+                         "extend_share_of_step": round(ext_s_local / (elapsed), 3), "shade_share_of_step": round(shade_s_local / elapsed, 3),
+                         # north_star: "VALU utilisation on intersection math" -- from the recorded SQ counter pass
+                         "valu_busy": recorded_valu("k_extend") if traffic else None},
         }
         if world == 1 and args.tree == "host" and not args.no_alt:
             # the same frame with the library's own SAH tree (hpt_scene_add_mesh(nodes = NULL)): identical hits by the

@@ -1,0 +1,33 @@
+"""profiles/<tag>_pmc_valu.json from the SQ counter summary scripts/gpu_pmc.sh wrote:
+   python3 scripts/make_valu_json.py profiles/<tag>_pmc_sq_counters.txt profiles/<tag>
+VALU busy fraction = SQ_ACTIVE_INST_VALU (quad-cycles the VALU pipes of all SIMDs spent issuing) * 4
+                     / (1024 SIMDs * kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 (summed over the 32 shader engines)."""
+import json, re, sys
+src, dst = sys.argv[1], sys.argv[2]
+txt = open(src).read().split("\n")
+SIMDS, SES = 256 * 4, 32
+
+
+def block(prefix):
+    out = {}
+    for i, l in enumerate(txt):
+        if l.startswith(prefix):
+            for m in txt[i + 1:]:
+                g = re.match(r"\s+(\S+)\s+total (\S+)\s+per-dispatch (\S+)\s+\(n=(\d+)\)", m)
+                if not g:
+                    break
+                out[g.group(1)] = float(g.group(3)); out["launches"] = int(g.group(4))
+            return out
+    raise SystemExit("no %s in %s" % (prefix, src))
+
+
+res = {"command": "rocprofv3 --pmc <8 SQ counters> -- python3 scripts/gpu_prof.py 8 (1080p teapot, passes of 4 spp = 8 M paths)",
+       "formula": "valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32 shader engines)"}
+for key, name in (("k_extend", "void k_extend<false, false"), ("k_shade", "void k_shade<true>")):
+    b = block(name)
+    cycles = b["SQ_BUSY_CYCLES"] / SES
+    res[key] = {"launches": b["launches"], "valu_wave_insts_per_launch": b["SQ_INSTS_VALU"], "salu_wave_insts_per_launch": b["SQ_INSTS_SALU"],
+                "kernel_cycles": round(cycles), "valu_busy_frac": round(b["SQ_ACTIVE_INST_VALU"] * 4 / (SIMDS * cycles), 4),
+                "wave_residency_frac": round(b["SQ_WAVE_CYCLES"] * 4 / (b["SQ_WAVES"] * cycles), 4)}
+json.dump(res, open(dst + "_pmc_valu.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
