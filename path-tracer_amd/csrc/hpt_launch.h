@@ -20,4 +20,5 @@ void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32
 void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n);
 void hptk_set_refill(int lanes);   // tuning: idle lanes per wave that trigger a refill in drain_queue
 size_t hptk_extend_lds_bytes(int stack_entries, const DScene& sc);   // dynamic LDS one k_extend workgroup asks for
-int hptk_extend_blocks_per_cu(int stack_entries, const DScene& sc);   // resident workgroups per CU (0: query failed)
+int hptk_extend_blocks_per_cu(int stack_entries, const DScene& sc);
+int hptk_shade_blocks_per_cu(const DScene& sc, int n_xf, int n_mat);   // resident workgroups of k_shade per CU (0: query failed)   // resident workgroups per CU (0: query failed)
