@@ -25,7 +25,7 @@
 #define HPT_EXTEND_WAVES 5       // instance-list kernel: 96 VGPRs (a few spills in the refill path); the two-level kernel (111 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
-#define HPT_SHADE_WAVES 5
+#define HPT_SHADE_WAVES 7
 #endif
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
