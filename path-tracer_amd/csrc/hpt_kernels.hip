@@ -245,13 +245,19 @@ __device__ __forceinline__ void test_children(const float4* __restrict__ nodes, 
 struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 
 // ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
-//   [stack: stack_entries x HPT_BLOCK ints][qn, qhead][queue: HPT_QUEUE_CAP uint2]
+// instance-list path (k_extend, k_trace_rays, k_scene_closest without a TLAS):
+//   [stack: stack_entries x HPT_BLOCK ints][16 B pad][rings: one per wave, HPT_QUEUE_CAP uint2 in all]
+//   [best: HPT_BLOCK keys][du, dv, dsf: HPT_BLOCK words each][ltri: per wave HPT_LEAF_CAP words][lown: per wave HPT_LEAF_CAP bytes]
+// two-level path: [stack][16 B pad] and, when analytic instances are deferred, [best][ltri]
 // (an LDS copy of the top tree levels was tried twice -- 16..1024 nodes -- and was 5 % slower each time: the second, LDS-side
 //  wait per step costs more than the fetches it saves)
 struct Lds {
-    int* stack; uint2* queue; unsigned* qn; unsigned* qhead; int refill; bool defer;
-    // deferred triangle tests of drain_queue (only carved when the queue is): per lane the best (t, triangle) key of the
-    // mesh it is walking + u, v, side of that hit; per wave a list of (triangle, owner lane) pairs waiting to be tested
+    int* stack;          // per-lane traversal stack, lane's column = stack + threadIdx.x, stride HPT_BLOCK
+    uint2* queue;        // ray rings (slot, first mesh instance to visit)
+    int refill;          // idle lanes at which a wave leaves its traversal loop to refill
+    bool defer;          // two-level path: analytic instances go through the pending list
+    // deferred tests: per lane the best key of the ray it owns (t | triangle, or t | instance | side) + u, v, side of
+    // that hit; per wave a pending list of (triangle or instance, owner lane) pairs waiting to be tested 64 at a time
     unsigned long long* best; float* du; float* dv; uint32_t* dsf; uint32_t* ltri; uint8_t* lown;
 };
 #define HPT_LEAF_CAP 192      // >= 63 left over + 2 appended per lane in one step
@@ -259,9 +265,7 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L;
     L.stack = (int*)lds_raw;
-    L.qn = (unsigned*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int));
-    L.qhead = L.qn + 1;
-    L.queue = (uint2*)(L.qn + 4);      // the two-level (TLAS) path launches without the queue and what follows it
+    L.queue = (uint2*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16);
     L.best = (unsigned long long*)(L.queue + HPT_QUEUE_CAP);
     L.du = (float*)(L.best + HPT_BLOCK);
     L.dv = L.du + HPT_BLOCK;
@@ -271,12 +275,12 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     L.refill = 24; L.defer = false;
     return L;
 }
-// two-level path: [stack][16 B][best key per lane][pending list per wave] (the last two only when `defer`: the host
-// asks for them when the scene has analytic instances and the extra 5 KB do not cost a resident workgroup)
+// (`defer`: the host asks for key + list when a quarter of the scene's instances are analytic and the extra 5 KB do not
+//  cost a resident workgroup)
 __device__ __forceinline__ Lds lds_carve_tlas(int stack_entries, bool defer) {
     Lds L = lds_carve(stack_entries);
     L.defer = defer;
-    L.best = (unsigned long long*)(L.qn + 4);
+    L.best = (unsigned long long*)L.queue;      // no rings on this path
     L.ltri = (uint32_t*)(L.best + HPT_BLOCK);
     return L;
 }
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
 }
 
 // ------------------------------------------------------------------------------------------------ k_scene_intersect
-// test entry for Scene::intersect: the same workgroup-cooperative closest hit as k_extend, then the HitInfo rebuild
+// test entry for Scene::intersect: the same closest-hit code as k_extend, then the HitInfo rebuild
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_scene_closest(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
                 float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, int stack_entries, int defer) {
