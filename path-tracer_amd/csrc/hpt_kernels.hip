@@ -22,7 +22,7 @@
 #define PI_F 3.14159265358979323846f
 // register budgets (waves per SIMD the allocator must reach) of the two hot kernels; see DESIGN.md tuning log
 #ifndef HPT_EXTEND_WAVES
-#define HPT_EXTEND_WAVES 5       // instance-list kernel: 96 VGPRs (a few spills in the refill path); the two-level kernel (111 VGPRs) stays at 4
+#define HPT_EXTEND_WAVES 5       // instance-list kernel: 85 VGPRs, 5 workgroups per CU by its 31.5 KB of LDS; the two-level kernel (101..118 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 7
