@@ -11,6 +11,7 @@ ctx = hpt.Context(0)
 sc = hpt.Scene(ctx, desc, host_bvh=lambda m: host_bvh.build_reference_bvh(m.verts, m.tris))
 out = torch.zeros(1920 * 1080 * 3, device="cuda")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=8, seed=1, spp_per_pass=4)
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # samples per pass (4 = 8 M paths; 32 = the bench's 66 M)
+st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=8, seed=1, spp_per_pass=S)
 print("rays", st.rays_primary + st.rays_bounce, "seconds", st.seconds_total)
 sc.close(); ctx.close()
