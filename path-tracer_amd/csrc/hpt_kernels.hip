@@ -30,10 +30,6 @@
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
 // lanes of a wave that must hold a leaf of one kind before its block runs (two-level kernel), see DESIGN.md
-// box steps between two rounds of work stealing at the end of a launch (instance-list kernel)
-#ifndef HPT_STEAL_STEPS
-#define HPT_STEAL_STEPS 8u
-#endif
 #ifndef HPT_PARK_TRI
 #define HPT_PARK_TRI 12
 #endif
@@ -465,14 +461,6 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     RayBox rb = make_raybox(lo, ld);
     float bound_s = HPT_INF;      // min(nearest triangle of this mesh as of the last batch, scene-level nearest) * HPT_SLACK
     int ref = SENTINEL, sp = 1, inst_idx = 0;
-    // work stealing at the end of the launch (nothing left to pull): a lane without box steps takes the BOTTOM stack entry
-    // -- the largest postponed subtree -- of a lane that has some, and walks it for that lane's ray: `own` = the lane
-    // whose ray (lo, ld, key) the steps belong to, `base` = first stack index not given away, helpers[l] = lanes
-    // still walking for lane l's ray (it merges its mesh only at 0).  The ring memory is free by then.
-    int own = (int)lane, base = 1; bool helping = false, steal_ready = false;
-    int* helpers = (int*)queue;
-    uint8_t* vtab = (uint8_t*)(helpers + 64);
-    const unsigned wbase = threadIdx.x & ~63u;
     for (;;) {
         // ---- phase 1 until a full wave of rays is queued (or the input ends)
         while (!feed.done() && qn - qhead < 64u) {
@@ -525,14 +513,9 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             }
         }
         const bool exhausted = feed.done() && qn == qhead;      // nothing left to pull, ever
-        if (exhausted) {
-            if (!steal_ready) { helpers[lane] = 0; steal_ready = true; }
-            if (helping && ref == SENTINEL) { atomicSub(helpers + own, 1); own = (int)lane; helping = false; }   // a stolen subtree is done
-        }
-        const bool mesh_done = have && !need_setup && ref == SENTINEL && !(exhausted && *(volatile int*)(helpers + lane) != 0);
         // ---- lanes whose mesh is finished (nothing of theirs is pending: the list was emptied below) merge its result
         //      and move on to the ray's next mesh instance
-        if (LOCAL && mesh_done) {
+        if (LOCAL && have && !need_setup && ref == SENTINEL) {
             const unsigned long long key = *mybest;
             if ((uint32_t)key != 0xffffffffu) {
                 const uint32_t sf = L.dsf[threadIdx.x];
@@ -542,7 +525,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             }
             have = false;
         }
-        if (!LOCAL && mesh_done) {
+        if (!LOCAL && have && !need_setup && ref == SENTINEL) {
             const unsigned long long key = *mybest;
             if ((uint32_t)key != 0xffffffffu) {
                 const float t = __uint_as_float((uint32_t)(key >> 32));
@@ -567,7 +550,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             rb = make_raybox(lo, ld);
             if (NODE32) rb = quant_slab(rb, lmesh->qbase, lmesh->qscale);
             bound_s = HPT_INF; *mybest = HPT_KEY_NONE;
-            stk[0] = SENTINEL; sp = 1; base = 1; ref = lmesh->root_ref;
+            stk[0] = SENTINEL; sp = 1; ref = lmesh->root_ref;
         }
         if (!LOCAL && need_setup) {
             const f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
@@ -589,47 +572,16 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), ht * HPT_SLACK, tin)) {
                     if (NODE32) rb = quant_slab(rb, mesh->qbase, mesh->qscale);   // from here on rb addresses the tree's 16-bit grid
                     bound_s = ht * HPT_SLACK; *mybest = HPT_KEY_NONE;
-                    stk[0] = SENTINEL; sp = 1; base = 1; ref = mesh->root_ref;
+                    stk[0] = SENTINEL; sp = 1; ref = mesh->root_ref;
                     break;
                 }
                 ++mpos;
             }
         }
-        if (exhausted) {      // ---- hand postponed subtrees to lanes that have nothing to walk
-            const bool can_give = ref != SENTINEL && sp > base, can_take = ref == SENTINEL;
-            const unsigned long long mg = __ballot(can_give), mt = __ballot(can_take);
-            if (mg != 0ull && mt != 0ull) {
-                const unsigned ng = (unsigned)__popcll(mg), nt = (unsigned)__popcll(mt), npair = ng < nt ? ng : nt;
-                const unsigned rg = lane_prefix(mg), rt = lane_prefix(mt);
-                const bool gives = can_give && rg < npair, takes = can_take && rt < npair;
-                int given = 0;
-                if (gives) {
-                    vtab[rg] = (uint8_t)lane;
-                    given = stk[base * HPT_BLOCK];
-                    stk[base * HPT_BLOCK] = SENTINEL;      // the walk of this lane now ends where the entry was
-                    ++base;
-                    atomicAdd(helpers + own, 1);
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int from = takes ? (int)vtab[rt] : (int)lane;
-                const int g = __shfl(given, from), ow = __shfl(own, from);
-                const float bs = __shfl(bound_s, from);
-                Slab vr;
-                vr.ax = __shfl(rb.ax, from); vr.ay = __shfl(rb.ay, from); vr.az = __shfl(rb.az, from);
-                vr.blx = __shfl(rb.blx, from); vr.bly = __shfl(rb.bly, from); vr.blz = __shfl(rb.blz, from);
-                vr.bhx = __shfl(rb.bhx, from); vr.bhy = __shfl(rb.bhy, from); vr.bhz = __shfl(rb.bhz, from);
-                if (takes) { ref = g; sp = 1; base = 1; stk[0] = SENTINEL; rb = vr; bound_s = bs; own = ow; helping = true; }
-            }
-        }
-        if (__ballot(have || ref != SENTINEL) == 0ull) { if (exhausted) break; else continue; }
-        // ---- box steps until enough lanes are done (once nothing is left to pull: all of them, with a stop every HPT_STEAL_STEPS steps
-        //      when some lanes are idle, so that they can take over postponed subtrees)
+        if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+        // ---- box steps until enough lanes are done (all of them once nothing is left to pull)
         const int keep_going_above = exhausted ? 0 : 64 - L.refill;
-        unsigned steps = 0;
-        while (true) {
-            const int active = __popcll(__ballot(ref != SENTINEL));
-            if (active <= keep_going_above) break;
-            if (exhausted && active < 64 && ++steps > HPT_STEAL_STEPS) break;
+        while (__popcll(__ballot(ref != SENTINEL)) > keep_going_above) {
             bool leafL = false, leafR = false; int l = 0, r = 0;
 #ifdef HPT_DEBUG_SLOTS      // tuning builds: lane slots of the inner loop are added to the instance-test counter
             if (COUNT && (HPT_DEBUG_SLOTS == 1 || (HPT_DEBUG_SLOTS == 2 && exhausted) || (HPT_DEBUG_SLOTS == 3 && !have))) n_inst++;
@@ -654,13 +606,13 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             }
             const unsigned long long mL = __ballot(leafL), mR = __ballot(leafR);
             if (mL | mR) {
-                if (leafL) { const unsigned e = lbase + pend + lane_prefix(mL); L.ltri[e] = (uint32_t)~l; L.lown[e] = (uint8_t)own; }
+                if (leafL) { const unsigned e = lbase + pend + lane_prefix(mL); L.ltri[e] = (uint32_t)~l; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mL);
-                if (leafR) { const unsigned e = lbase + pend + lane_prefix(mR); L.ltri[e] = (uint32_t)~r; L.lown[e] = (uint8_t)own; }
+                if (leafR) { const unsigned e = lbase + pend + lane_prefix(mR); L.ltri[e] = (uint32_t)~r; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mR);
                 if (pend >= 64u) {
                     do { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); } while (pend >= 64u);
-                    bound_s = fminf(bound_s, __uint_as_float((uint32_t)(*(volatile unsigned long long*)(L.best + wbase + own) >> 32)) * HPT_SLACK);
+                    bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
                 }
             }
         }
@@ -670,7 +622,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             pend -= n;
             test_pending<COUNT>(L, tris, pend, n, lo, ld, n_tri);
         }
-        bound_s = fminf(bound_s, __uint_as_float((uint32_t)(*(volatile unsigned long long*)(L.best + wbase + own) >> 32)) * HPT_SLACK);
+        bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
     }
 }
 
