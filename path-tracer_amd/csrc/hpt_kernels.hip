@@ -582,15 +582,15 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
         // ---- box steps until enough lanes are done (all of them once nothing is left to pull)
         const int keep_going_above = exhausted ? 0 : 64 - L.refill;
         while (__popcll(__ballot(ref != SENTINEL)) > keep_going_above) {
-            bool leafL = false, leafR = false; int l = 0, r = 0;
+            int cl = 0, cr = 0;      // child refs that are leaves whose box the ray enters (negative), else 0
 #ifdef HPT_DEBUG_SLOTS      // tuning builds: lane slots of the inner loop are added to the instance-test counter
             if (COUNT && (HPT_DEBUG_SLOTS == 1 || (HPT_DEBUG_SLOTS == 2 && exhausted) || (HPT_DEBUG_SLOTS == 3 && !have))) n_inst++;
 #endif
             if (ref >= 0) {
                 if (COUNT) n_int++;
-                bool hitL, hitR; float tinL, tinR;
+                bool hitL, hitR; float tinL, tinR; int l, r;
                 test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r);
-                leafL = hitL && l < 0; leafR = hitR && r < 0;
+                cl = hitL ? min(l, 0) : 0; cr = hitR ? min(r, 0) : 0;
                 const bool intL = hitL && l >= 0, intR = hitR && r >= 0;
                 if (intL && intR) {
                     const bool lfirst = tinL < tinR;
@@ -601,14 +601,14 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 else if (intR) ref = r;
                 else { --sp; ref = stk[sp * HPT_BLOCK]; }
             } else if (ref != SENTINEL) {      // a mesh whose root is a leaf
-                leafL = true; l = ref;
+                cl = ref;
                 --sp; ref = stk[sp * HPT_BLOCK];
             }
-            const unsigned long long mL = __ballot(leafL), mR = __ballot(leafR);
+            const unsigned long long mL = __ballot(cl < 0), mR = __ballot(cr < 0);
             if (mL | mR) {
-                if (leafL) { const unsigned e = lbase + pend + lane_prefix(mL); L.ltri[e] = (uint32_t)~l; L.lown[e] = (uint8_t)lane; }
+                if (cl < 0) { const unsigned e = lbase + pend + lane_prefix(mL); L.ltri[e] = (uint32_t)~cl; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mL);
-                if (leafR) { const unsigned e = lbase + pend + lane_prefix(mR); L.ltri[e] = (uint32_t)~r; L.lown[e] = (uint8_t)lane; }
+                if (cr < 0) { const unsigned e = lbase + pend + lane_prefix(mR); L.ltri[e] = (uint32_t)~cr; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mR);
                 if (pend >= 64u) {
                     do { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); } while (pend >= 64u);
