@@ -592,14 +592,12 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r);
                 cl = hitL ? min(l, 0) : 0; cr = hitR ? min(r, 0) : 0;
                 const bool intL = hitL && l >= 0, intR = hitR && r >= 0;
-                if (intL && intR) {
-                    const bool lfirst = tinL < tinR;
-                    stk[sp * HPT_BLOCK] = lfirst ? r : l;
-                    sp++;
-                    ref = lfirst ? l : r;
-                } else if (intL) ref = l;
-                else if (intR) ref = r;
-                else { --sp; ref = stk[sp * HPT_BLOCK]; }
+                // flat form (two one-level predicated LDS operations instead of a three-level branch nest)
+                const bool lfirst = intL && (!intR || tinL < tinR);
+                int next = lfirst ? l : r;
+                if (intL && intR) { stk[sp * HPT_BLOCK] = lfirst ? r : l; sp++; }
+                if (!(intL || intR)) { --sp; next = stk[sp * HPT_BLOCK]; }
+                ref = next;
             } else if (ref != SENTINEL) {      // a mesh whose root is a leaf
                 cl = ref;
                 --sp; ref = stk[sp * HPT_BLOCK];
