@@ -1,5 +1,5 @@
 """profiles/<tag>_pmc_valu.json from the SQ counter summary scripts/gpu_pmc.sh wrote:
-   python3 scripts/make_valu_json.py profiles/<tag>_pmc_sq_counters.txt profiles/<tag>
+   python3 scripts/make_valu_json.py profiles/<tag>_pmc_sq_counters.txt profiles/<tag> ["<gpu_prof.py arguments and what they mean>"]
 VALU busy fraction = SQ_ACTIVE_INST_VALU (quad-cycles the VALU pipes of all SIMDs spent issuing) * 4
                      / (1024 SIMDs * kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 (summed over the 32 shader engines)."""
 import json, re, sys
@@ -21,7 +21,8 @@ def block(prefix):
     raise SystemExit("no %s in %s" % (prefix, src))
 
 
-res = {"command": "rocprofv3 --pmc <8 SQ counters> -- python3 scripts/gpu_prof.py 8 (1080p teapot, passes of 4 spp = 8 M paths)",
+what = sys.argv[3] if len(sys.argv) > 3 else "8 (1080p teapot, passes of 4 spp = 8 M paths)"
+res = {"command": "rocprofv3 --pmc <8 SQ counters> -- python3 scripts/gpu_prof.py " + what,
        "formula": "valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32 shader engines)"}
 for key, name in (("k_extend", "void k_extend<false, false"), ("k_shade", "void k_shade<true>")):
     b = block(name)
