@@ -74,7 +74,10 @@ typedef struct {
 
 enum {
     HPT_RENDER_COUNTERS = 1u,      /* run the instrumented extend kernel: fills nodes_visited / tris_tested / inst_tests */
-    HPT_RENDER_TIME_KERNELS = 2u   /* bracket every kernel with HIP events on the context stream; fills seconds_* */
+    HPT_RENDER_TIME_KERNELS = 2u   /* bracket every kernel with HIP events on the context stream; fills seconds_*.  Runs the
+                                      passes one after the other on that stream (without the flag a render keeps two
+                                      wavefront passes in flight, the second on a stream of the library's own, joined
+                                      back into the context stream before the call's work ends; same results bit for bit) */
 };
 
 /* replaces the constants of main.rs:27-32 and the loop bounds of main.rs:67-107 */

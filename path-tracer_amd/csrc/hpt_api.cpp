@@ -57,9 +57,15 @@ static int upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ context / scene
+#define HPT_MAX_INFLIGHT 4
 struct hpt_context {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // two passes in flight (render_range): odd passes run on aux_stream with a workspace of their own, so the ends of one
+    // pass's launches (a persistent grid drains unevenly) are filled by the other pass's kernels
+    hipStream_t aux_stream[HPT_MAX_INFLIGHT - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_done[HPT_MAX_INFLIGHT] = {};
+    int overlap = 2;            // passes in flight (1 = one stream)
     int num_cus = 256;
     int max_blocks = 2048;
     int extend_blocks = 1024;   // persistent grid of the test-entry traversal kernels
@@ -95,6 +101,7 @@ struct hpt_scene {
     int32_t tlas_nodes = 0, node_bytes = 64; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
     DevBuf w_q[2][3], w_hit, w_hit_inst, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
+    struct PassBufs { DevBuf q[2][3], hit, hit_inst, radiance, counts; } x[HPT_MAX_INFLIGHT - 1];   // pass buffers of the further passes in flight
     // trace workspace
     DevBuf t_org, t_dir, t_hit, t_side, t_misc[9];
 };
@@ -176,7 +183,11 @@ extern "C" int hpt_context_create(int device, hpt_context** out) {
     c->max_blocks = c->num_cus * 8;
     c->extend_blocks = c->num_cus * 4;
     if (const char* e = getenv("HPT_EXTEND_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->extend_per_cu = v; }
+    if (const char* e = getenv("HPT_OVERLAP")) c->overlap = std::min(std::max(atoi(e), 1), HPT_MAX_INFLIGHT);
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    for (hipStream_t& a : c->aux_stream) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (hipEvent_t& e : c->ev_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->stream = c->own_stream;
     *out = c;
     return HPT_OK;
@@ -185,6 +196,9 @@ extern "C" void hpt_context_destroy(hpt_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_done) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t a : c->aux_stream) if (a) (void)hipStreamDestroy(a);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -221,6 +235,10 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
                      &s->t_org, &s->t_dir, &s->t_hit, &s->t_side};
     for (DevBuf* b : all) b->release();
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) s->w_q[a][k].release();
+    for (auto& x : s->x) {
+        x.hit.release(); x.hit_inst.release(); x.radiance.release(); x.counts.release();
+        for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) x.q[a][k].release();
+    }
     for (DevBuf& b : s->t_misc) b.release();
     delete s;
 }
@@ -727,9 +745,12 @@ static int extend_grid(const hpt_scene* s) {
     return ctx->num_cus * std::max(1, per_cu);
 }
 
-static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks) {
+// `st`: the stream of this pass; `after` (may be null): the resolve of the previous pass, on the other stream -- sums
+// go into `accum` in sample order, so the resolves of consecutive passes are chained; `done` (may be null) is recorded
+// behind this pass's resolve.
+static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks,
+                    hipStream_t st, hipEvent_t after, hipEvent_t done) {
     hpt_context* ctx = s->ctx;
-    hipStream_t st = ctx->stream;
     HIPCHK(hipMemsetAsync(ps.counts, 0, (size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(ps.radiance, 0, (size_t)ps.n_slots * ps.S * sizeof(float4), st));
     CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps); CHK(ev.end(st));
@@ -744,9 +765,11 @@ static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool c
         CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->stack_entries, s->ds, ps, depth, counters); CHK(ev.end(st));
         CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->ds, ps, depth, s->n_xf, s->n_mat); CHK(ev.end(st));
     }
+    if (after) HIPCHK(hipStreamWaitEvent(st, after, 0));
     CHK(ev.begin(3, st)); hptk_resolve(st, ctx->max_blocks, ps, accum, minmax); CHK(ev.end(st));
     hptk_finish_pass(st, ps);
     HIPCHK(hipGetLastError());
+    if (done) HIPCHK(hipEventRecord(done, st));
     return HPT_OK;
 }
 
@@ -754,16 +777,19 @@ static uint32_t shard_cap_for(uint64_t n_paths) {
     const uint64_t chunks = (n_paths + HPT_BLOCK - 1) / HPT_BLOCK;
     return (uint32_t)(((chunks + HPT_SHARDS - 1) / HPT_SHARDS) * HPT_BLOCK);
 }
-static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps) {
+static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps, int set) {
     if (n_paths >= (1ull << 31) - (1ull << 20)) return fail(HPT_ERR_LIMIT, "render: more than 2^31 paths per pass; lower spp_per_pass");
     const uint64_t max_paths = (uint64_t)shard_cap_for(n_paths) * HPT_SHARDS;   // slots of a sharded queue
-    for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(s->w_q[a][k].ensure(max_paths * 16));
-    CHK(s->w_hit.ensure(max_paths * 16)); CHK(s->w_hit_inst.ensure(max_paths * 4)); CHK(s->w_radiance.ensure(max_paths * 16));
-    CHK(s->w_counts.ensure((size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t)));
+    DevBuf (&q)[2][3] = set ? s->x[set - 1].q : s->w_q;
+    DevBuf &hit = set ? s->x[set - 1].hit : s->w_hit, &hit_inst = set ? s->x[set - 1].hit_inst : s->w_hit_inst,
+           &radiance = set ? s->x[set - 1].radiance : s->w_radiance, &counts = set ? s->x[set - 1].counts : s->w_counts;
+    for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(q[a][k].ensure(max_paths * 16));
+    CHK(hit.ensure(max_paths * 16)); CHK(hit_inst.ensure(max_paths * 4)); CHK(radiance.ensure(max_paths * 16));
+    CHK(counts.ensure((size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
-    for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = s->w_q[a][0].as<float4>(); ps.q[a].ray_d = s->w_q[a][1].as<float4>(); ps.q[a].thr = s->w_q[a][2].as<float4>(); }
-    ps.hit = s->w_hit.as<float4>(); ps.hit_inst = s->w_hit_inst.as<uint32_t>(); ps.radiance = s->w_radiance.as<float4>();
-    ps.counts = s->w_counts.as<uint32_t>(); ps.stat = s->w_stat.as<unsigned long long>();
+    for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = q[a][0].as<float4>(); ps.q[a].ray_d = q[a][1].as<float4>(); ps.q[a].thr = q[a][2].as<float4>(); }
+    ps.hit = hit.as<float4>(); ps.hit_inst = hit_inst.as<uint32_t>(); ps.radiance = radiance.as<float4>();
+    ps.counts = counts.as<uint32_t>(); ps.stat = s->w_stat.as<unsigned long long>();
     return HPT_OK;
 }
 
@@ -793,21 +819,32 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
     const uint64_t npix = n_active;
     if (npix == 0) return HPT_OK;
     const int S = std::min(default_spp_per_pass(npix, p->spp_per_pass), p->spp);
-    DPass ps; std::memset(&ps, 0, sizeof ps);
-    CHK(ensure_pass_workspace(s, npix * (uint64_t)S, ps));
+    // Two passes in flight when there are at least two: pass k runs on stream k & 1 with pass buffers of its own.  The
+    // per-kernel event timing of HPT_RENDER_TIME_KERNELS needs launches that have the GPU to themselves: one stream then.
+    const int n_passes = (p->spp + S - 1) / S;
+    const int inflight = (per_sample_host || ev.on) ? 1 : std::min(ctx->overlap, n_passes);
+    DPass psv[HPT_MAX_INFLIGHT]; std::memset(psv, 0, sizeof psv);
+    for (int k = 0; k < inflight; ++k) CHK(ensure_pass_workspace(s, npix * (uint64_t)S, psv[k], k));
     std::vector<float> hal((size_t)p->spp * 2);
     for (int k = 0; k < p->spp; ++k) { hal[2 * k] = hpt_halton(p->first_sample + k + 1, 2); hal[2 * k + 1] = hpt_halton(p->first_sample + k + 1, 3); }
     CHK(upload(s->w_halton, hal, st));
     HIPCHK(hipStreamSynchronize(st));   // `hal` is pageable host memory
     std::vector<float> rad;
     uint32_t passes = 0;
+    if (inflight > 1) {
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        for (int k = 1; k < inflight; ++k) HIPCHK(hipStreamWaitEvent(ctx->aux_stream[k - 1], ctx->ev_fork, 0));
+    }
     for (int done = 0; done < p->spp; done += S) {
         const int cur = std::min(S, p->spp - done);
+        const int set = (int)(passes % (uint32_t)inflight);
+        DPass& ps = psv[set];
         ps.halton = s->w_halton.as<float2>() + done;
         ps.pixel_list = pixel_list; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
         ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
         ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
-        CHK(run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s)));
+        CHK(run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s), set ? ctx->aux_stream[set - 1] : st,
+                     inflight > 1 && passes > 0 ? ctx->ev_done[(set + inflight - 1) % inflight] : nullptr, inflight > 1 ? ctx->ev_done[set] : nullptr));
         ++passes;
         if (per_sample_host) {
             rad.resize((size_t)npix * cur * 4);
@@ -818,6 +855,8 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
                     for (int c = 0; c < 3; ++c) per_sample_host[(px * (uint64_t)p->spp + (uint64_t)(done + k)) * 3 + c] = rad[((uint64_t)k * npix + px) * 4 + c];      // radiance is sample-major
         }
     }
+    // the last pass's resolve is behind every other one (chain); the context stream continues behind it
+    if (inflight > 1 && (passes - 1) % (uint32_t)inflight != 0u) HIPCHK(hipStreamWaitEvent(st, ctx->ev_done[(passes - 1) % (uint32_t)inflight], 0));
     if (stats) { stats->passes += passes; stats->samples += npix * (uint64_t)p->spp; }
     return HPT_OK;
 }
@@ -995,4 +1034,5 @@ extern "C" int hpt_scene_info(hpt_scene* s, hpt_scene_info_t* out) {
 // ------------------------------------------------------------------------------------------------ tuning hooks
 // Not part of include/hpt.h: used by scripts/gpu_time.py for interleaved A/B runs inside one process.
 extern "C" void hpt_debug_set_refill(int lanes) { hptk_set_refill(lanes); }
+extern "C" void hpt_debug_set_overlap(hpt_context* ctx, int n) { if (ctx) ctx->overlap = std::min(std::max(n, 1), HPT_MAX_INFLIGHT); }
 extern "C" void hpt_debug_set_extend_blocks(hpt_context* ctx, int per_cu) { if (ctx && per_cu >= 0 && per_cu <= 16) ctx->extend_per_cu = per_cu; }

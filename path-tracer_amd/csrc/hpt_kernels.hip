@@ -1415,13 +1415,14 @@ void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc
 }
 // resident workgroups of k_shade per CU (0: query failed); the pass launches a multiple of it -- work is strided
 // statically over the grid, so a grid of 1.6 x the resident workgroups runs one full round and one at 60 %
+static bool shade_tables_in_lds(size_t tables) { return tables <= 24 * 1024; }
 int hptk_shade_blocks_per_cu(const DScene& sc, int n_xf, int n_mat) {
     const size_t tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
-    return tables <= 24 * 1024 ? resident_blocks(k_shade<true>, tables) : resident_blocks(k_shade<false>, 0);
+    return shade_tables_in_lds(tables) ? resident_blocks(k_shade<true>, tables) : resident_blocks(k_shade<false>, 0);
 }
 void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {
     const size_t tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
-    if (tables <= 24 * 1024) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(HPT_BLOCK), tables, st, sc, ps, depth, n_xf, n_mat);
+    if (shade_tables_in_lds(tables)) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(HPT_BLOCK), tables, st, sc, ps, depth, n_xf, n_mat);
     else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth, n_xf, n_mat);
 }
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax) {
