@@ -13,9 +13,11 @@
  *  - matrices are 3x3 COLUMN-major float[9] (m[c*3+r]) like cgmath::Matrix3 (scene.rs:102-105 Transform).
  *  - one hpt_context drives ONE GPU from one host thread (one process per GPU); multi-GPU = one context per rank,
  *    each rendering a sample range (first_sample, spp) of every pixel, summed afterwards (RCCL; see bench.py).
- *  - a context is not thread-safe.  All work of a context is enqueued on one HIP stream (its own, or the one
- *    given to hpt_context_set_stream); host-pointer entry points synchronise that stream before returning,
- *    *_device entry points do not.
+ *  - a context is not thread-safe.  All work of a context is ordered on one HIP stream (its own, or the one
+ *    given to hpt_context_set_stream): it starts behind what that stream holds and is complete when that stream
+ *    reaches the end of the call's work (a render runs every other pass on a second stream of the library's own,
+ *    forked from and joined back into the context stream); host-pointer entry points synchronise that stream before
+ *    returning, *_device entry points do not.
  */
 #ifndef HPT_H
 #define HPT_H

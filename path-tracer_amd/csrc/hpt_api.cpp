@@ -183,7 +183,7 @@ extern "C" int hpt_context_create(int device, hpt_context** out) {
     c->max_blocks = c->num_cus * 8;
     c->extend_blocks = c->num_cus * 4;
     if (const char* e = getenv("HPT_EXTEND_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 16) c->extend_per_cu = v; }
-    if (const char* e = getenv("HPT_OVERLAP")) c->overlap = std::min(std::max(atoi(e), 1), HPT_MAX_INFLIGHT);
+    if (const char* e = getenv("HPT_PASSES_IN_FLIGHT")) c->overlap = std::min(std::max(atoi(e), 1), HPT_MAX_INFLIGHT);
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     for (hipStream_t& a : c->aux_stream) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

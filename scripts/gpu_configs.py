@@ -19,14 +19,19 @@ def run(ctx, name, desc, spp, depth, tree=None, S=0):
     cst = sc.render_device(out.data_ptr(), want_stats=True, spp=min(spp, 4), max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_COUNTERS)
     st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_TIME_KERNELS)
     rays = st.rays_primary + st.rays_bounce; cr = cst.rays_primary + cst.rays_bounce
+    # library default (two passes in flight; needs >= 2 passes): wall clock of a render without the event timing
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    wst = sc.render_device(out.data_ptr(), want_stats=True, spp=2 * spp, max_depth=depth, seed=1, spp_per_pass=S)
+    torch.cuda.synchronize(); wall = time.perf_counter() - t1
     info = sc.info()
     bpr = (info.node_bytes * float(cst.nodes_visited) + 48.0 * cst.tris_tested + (128.0 * cst.inst_tests if info.uses_tlas else 0.0)) / cr + 52
     rec = {"config": name, "res": [desc.camera.width, desc.camera.height], "spp": spp, "depth": depth, "commit_s": round(t_commit, 3), "scene_MB": round(info.device_bytes / 1e6, 1), "tlas": int(info.uses_tlas),
-           "seconds": round(st.seconds_total, 4), "Mrays_s": round(rays / st.seconds_total / 1e6, 1), "rays_per_sample": round(rays / (npix * spp), 3),
+           "seconds": round(st.seconds_total, 4), "Mrays_s": round((wst.rays_primary + wst.rays_bounce) / wall / 1e6, 1), "passes": int(wst.passes),
+           "Mrays_s_one_stream": round(rays / st.seconds_total / 1e6, 1), "rays_per_sample": round(rays / (npix * spp), 3),
            "extend_s": round(st.seconds_extend, 4), "shade_s": round(st.seconds_shade, 4), "extend_Grays_s": round(rays / st.seconds_extend / 1e9, 3),
            "nodes_per_ray": round(cst.nodes_visited / cr, 2), "tris_per_ray": round(cst.tris_tested / cr, 2), "inst_per_ray": round(cst.inst_tests / cr, 2),
            "bytes_per_ray": round(bpr, 1), "extend_GBs": round(bpr * rays / st.seconds_extend / 1e9, 1),
-           "image_mean": [round(float(v), 5) for v in (out.view(-1, 3).mean(dim=0) / spp).cpu()]}
+           "image_mean": [round(float(v), 5) for v in (out.view(-1, 3).mean(dim=0) / (2 * spp)).cpu()]}
     print(json.dumps(rec), flush=True)
     sc.close()
 
