@@ -229,6 +229,7 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    for (hipStream_t a : s->ctx->aux_stream) if (a) (void)hipStreamSynchronize(a);   // (joined already unless a render failed half way)
     DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_materials,
                      &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
                      &s->w_accum, &s->w_minmax, &s->w_spp, &s->w_list[0], &s->w_list[1], &s->w_listcount, &s->w_out,
