@@ -833,9 +833,11 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
     // Two passes in flight when there are at least two: pass k runs on stream k & 1 with pass buffers of its own.  The
     // per-kernel event timing of HPT_RENDER_TIME_KERNELS needs launches that have the GPU to themselves: one stream then.
     const int n_passes = (p->spp + S - 1) / S;
-    const int inflight = (per_sample_host || ev.on) ? 1 : std::min(ctx->overlap, n_passes);
+    int inflight = (per_sample_host || ev.on) ? 1 : std::min(ctx->overlap, n_passes);
     DPass psv[HPT_MAX_INFLIGHT]; std::memset(psv, 0, sizeof psv);
-    for (int k = 0; k < inflight; ++k) CHK(ensure_pass_workspace(s, npix * (uint64_t)S, psv[k], k));
+    CHK(ensure_pass_workspace(s, npix * (uint64_t)S, psv[0], 0));
+    for (int k = 1; k < inflight; ++k)
+        if (ensure_pass_workspace(s, npix * (uint64_t)S, psv[k], k) != HPT_OK) { inflight = k; (void)hipGetLastError(); break; }   // no memory for another set of pass buffers: fewer in flight
     std::vector<float> hal((size_t)p->spp * 2);
     for (int k = 0; k < p->spp; ++k) { hal[2 * k] = hpt_halton(p->first_sample + k + 1, 2); hal[2 * k + 1] = hpt_halton(p->first_sample + k + 1, 3); }
     CHK(upload(s->w_halton, hal, st));
