@@ -20,6 +20,7 @@ def main():
     sc = hpt.Scene(ctx, d, host_bvh=(lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if tree else None)
     with torch.cuda.stream(stream):
         outs = [torch.zeros(1920 * 1080 * 3, device="cuda") for _ in range(2)]
+    if os.environ.get("HPT_REFILL"): hpt.lib.hpt_debug_set_refill(int(os.environ["HPT_REFILL"]))
     sc.render_device(outs[0].data_ptr(), want_stats=True, spp=64, max_depth=8, seed=1)
     for S in spps:
         for rep in range(2):
