@@ -829,7 +829,10 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
     hipStream_t st = ctx->stream;
     const uint64_t npix = n_active;
     if (npix == 0) return HPT_OK;
-    const int S = std::min(default_spp_per_pass(npix, p->spp_per_pass), p->spp);
+    int S = std::min(default_spp_per_pass(npix, p->spp_per_pass), p->spp);
+    // a render that would be ONE big pass runs as two halves, so that two passes can be in flight (results do not depend on the split)
+    if (p->spp_per_pass == 0 && S == p->spp && S >= 2 && ctx->overlap > 1 && !per_sample_host && !ev.on && npix * (uint64_t)S >= (16ull << 20))
+        S = (S + 1) / 2;
     // Two passes in flight when there are at least two: pass k runs on stream k & 1 with pass buffers of its own.  The
     // per-kernel event timing of HPT_RENDER_TIME_KERNELS needs launches that have the GPU to themselves: one stream then.
     const int n_passes = (p->spp + S - 1) / S;
