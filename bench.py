@@ -151,7 +151,7 @@ def main():
     desc.camera.width, desc.camera.height = args.width, args.height
     ctx = hpt.Context(device_index)
     if args.inflight > 0:
-        hpt.lib.hpt_debug_set_overlap(ctx.h, args.inflight)
+        ctx.set_passes_in_flight(args.inflight)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
     tree = (lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if args.tree == "host" else None

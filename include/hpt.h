@@ -142,6 +142,10 @@ void hpt_context_destroy(hpt_context* ctx);
 /* use the caller's hipStream_t (e.g. torch's current stream) for all later work; NULL = back to the context's own */
 int hpt_context_set_stream(hpt_context* ctx, void* hip_stream);
 int hpt_context_synchronize(hpt_context* ctx);
+/* wavefront passes a render keeps in flight: 1 = everything on the context stream, 2 (default) = every other pass on a
+ * second stream of the library's own with a second set of pass buffers (+8.9 GB at the default pass size), up to 4.
+ * No counterpart in the reference (main.rs:57 is one rayon loop); results do not depend on it. */
+int hpt_context_set_passes_in_flight(hpt_context* ctx, int n);
 
 /* ---- scene building: what load_scene (load.rs:17) returns, handed over piece by piece ---- */
 int hpt_scene_create(hpt_context* ctx, hpt_scene** out);

@@ -209,6 +209,12 @@ extern "C" int hpt_context_set_stream(hpt_context* c, void* s) {
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return HPT_OK;
 }
+extern "C" int hpt_context_set_passes_in_flight(hpt_context* c, int n) {
+    if (!c) return fail(HPT_ERR_INVALID, "null context");
+    if (n < 1 || n > HPT_MAX_INFLIGHT) return fail(HPT_ERR_INVALID, "passes in flight must be in 1..%d", HPT_MAX_INFLIGHT);
+    c->overlap = n;
+    return HPT_OK;
+}
 extern "C" int hpt_context_synchronize(hpt_context* c) {
     if (!c) return fail(HPT_ERR_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));

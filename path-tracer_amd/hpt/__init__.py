@@ -68,6 +68,7 @@ class SceneInfo(C.Structure):
 EXPORTS = [
     "hpt_version", "hpt_last_error", "hpt_device_count", "hpt_rng_f32", "hpt_halton", "hpt_tonemap_rgba8",
     "hpt_context_create", "hpt_context_destroy", "hpt_context_set_stream", "hpt_context_synchronize",
+    "hpt_context_set_passes_in_flight",
     "hpt_scene_create", "hpt_scene_destroy", "hpt_scene_add_mesh", "hpt_scene_add_image", "hpt_scene_add_material",
     "hpt_scene_add_node", "hpt_scene_set_background", "hpt_scene_set_environment", "hpt_scene_set_camera", "hpt_scene_commit",
     "hpt_trace_rays", "hpt_trace_rays_device", "hpt_scene_intersect", "hpt_render", "hpt_render_device", "hpt_render_samples",
@@ -116,6 +117,7 @@ def _load():
     lib.hpt_context_destroy.argtypes = [C.c_void_p]
     lib.hpt_context_destroy.restype = None
     lib.hpt_context_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hpt_context_set_passes_in_flight.argtypes = [C.c_void_p, C.c_int]
     lib.hpt_context_synchronize.argtypes = [C.c_void_p]
     lib.hpt_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.hpt_scene_destroy.argtypes = [C.c_void_p]
@@ -193,6 +195,9 @@ class Context:
 
     def set_stream(self, stream_ptr):
         check(lib.hpt_context_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_passes_in_flight(self, n):
+        check(lib.hpt_context_set_passes_in_flight(self.h, int(n)))
 
     def synchronize(self):
         check(lib.hpt_context_synchronize(self.h))

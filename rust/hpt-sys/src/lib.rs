@@ -84,6 +84,7 @@ extern "C" {
     pub fn hpt_context_create(device: c_int, out: *mut *mut hpt_context) -> c_int;
     pub fn hpt_context_destroy(ctx: *mut hpt_context);
     pub fn hpt_context_set_stream(ctx: *mut hpt_context, hip_stream: *mut c_void) -> c_int;
+    pub fn hpt_context_set_passes_in_flight(ctx: *mut hpt_context, n: c_int) -> c_int;
     pub fn hpt_context_synchronize(ctx: *mut hpt_context) -> c_int;
 
     pub fn hpt_scene_create(ctx: *mut hpt_context, out: *mut *mut hpt_scene) -> c_int;

@@ -292,10 +292,10 @@ def test_passes_in_flight_do_not_change_results(ctx, desc):
     out = [torch.zeros(96 * 64 * 3, device="cuda", dtype=torch.float32) for _ in range(2)]
     try:
         for spp, per_pass in ((8, 4), (12, 4), (13, 3), (5, 1), (3, 4)):
-            hpt.lib.hpt_debug_set_overlap(ctx.h, 1)
+            ctx.set_passes_in_flight(1)
             a = gsc.render_device(out[0].data_ptr(), want_stats=True, spp=spp, max_depth=8, seed=3, spp_per_pass=per_pass, flags=hpt.RENDER_COUNTERS)
             for n in (2, 3, 4):
-                hpt.lib.hpt_debug_set_overlap(ctx.h, n)
+                ctx.set_passes_in_flight(n)
                 out[1].fill_(-1.0)
                 b = gsc.render_device(out[1].data_ptr(), want_stats=True, spp=spp, max_depth=8, seed=3, spp_per_pass=per_pass, flags=hpt.RENDER_COUNTERS)
                 torch.cuda.synchronize()
@@ -303,12 +303,12 @@ def test_passes_in_flight_do_not_change_results(ctx, desc):
                 assert (a.rays_primary, a.rays_bounce, a.passes) == (b.rays_primary, b.rays_bounce, b.passes)
                 # work counters are not results: how many boxes a ray visits depends on when its wave refreshes the culling bound
                 assert abs(a.nodes_visited - b.nodes_visited) <= 0.01 * a.nodes_visited and abs(a.tris_tested - b.tris_tested) <= 0.01 * a.tris_tested
-        hpt.lib.hpt_debug_set_overlap(ctx.h, 1)
+        ctx.set_passes_in_flight(1)
         g1 = gsc.render(adaptive=True, initial=8, max_samples=32, max_depth=8, seed=1, spp_per_pass=2)
-        hpt.lib.hpt_debug_set_overlap(ctx.h, 2)
+        ctx.set_passes_in_flight(2)
         g2 = gsc.render(adaptive=True, initial=8, max_samples=32, max_depth=8, seed=1, spp_per_pass=2)
         np.testing.assert_array_equal(g1["samples"], g2["samples"])
         np.testing.assert_array_equal(g1["rgb"], g2["rgb"])
     finally:
-        hpt.lib.hpt_debug_set_overlap(ctx.h, 2)
+        ctx.set_passes_in_flight(2)
         gsc.close()
