@@ -45,6 +45,16 @@ def check_scene(ctx, olib, desc, n_rays, spp, depth, host_bvh=None, img_tol=2e-3
     assert abs(nr - ref["stats"].rays) <= max(20, ref["stats"].rays // 20000)
     rel = float(np.sqrt(((img["rgb"] - ref["rgb"]) ** 2).mean()) / ref["rgb"].mean())
     assert rel <= img_tol, rel
+    # the same frame as two passes in flight on two streams (and on one): the per-pixel sums run in sample order either way
+    img2 = gsc.render(spp=spp, max_depth=depth, seed=1, spp_per_pass=max(1, spp // 2))
+    assert img2["stats"].passes >= 2
+    np.testing.assert_array_equal(img2["rgb"], img["rgb"])
+    ctx.set_passes_in_flight(1)
+    try:
+        img1 = gsc.render(spp=spp, max_depth=depth, seed=1, spp_per_pass=max(1, spp // 2))
+    finally:
+        ctx.set_passes_in_flight(2)
+    np.testing.assert_array_equal(img1["rgb"], img["rgb"])
     gsc.close()
     return (r["node"] >= 0).mean()
 
