@@ -12,9 +12,13 @@ Inputs are resident in HBM before the timed region (the scene is committed once)
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+  python bench.py --config soup|instanced|spheres ...     the other BASELINE.json configs at full size (not the driver's line)
+
 Extra objects on the JSON line: "roofline" (k_extend: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak;
 the event-bracketed launches are the same K steps run once more on ONE stream, right after the timed region: with two
-passes in flight the event interval of a launch would also cover the other pass's kernels sharing the GPU with it)
+passes in flight the event interval of a launch would also cover the other pass's kernels sharing the GPU with it;
+`hbm_physical` / `valu` = the committed rocprofv3 counter passes of the same frame, flagged `stale` when they were
+taken with other kernel sources than the tree holds; `limiter` = which of the two is closer to its peak)
 and "cpu_baseline" (the C restatement of the reference -- oracle/liboracle_fast.so -- on the host cores, rank 0, N=1).
 """
 import argparse
@@ -35,34 +39,45 @@ HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s sp
 EXTEND_QUEUE_BYTES = 52    # per ray in k_extend itself: ray_o + ray_d read (32 B), hit + hit_inst written (20 B)
 
 
-def recorded_traffic(kernel):
+def tree_sha256():
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from source_stamp import source_sha256
+    return source_sha256(ROOT)
+
+
+def _newest_profile(pattern, config="teapot"):
+    """newest (by file name: rNN_x_...) committed counter recording of `config`; the teapot's carry no config tag"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get("config", "teapot") == config:
+            return rec, os.path.relpath(f, ROOT)
+    return None, None
+
+
+def recorded_traffic(kernel, config="teapot"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share
     a pass, and counters cannot be read from inside this process): the newest profiles/*_pmc_traffic.json written by
-    scripts/gpu_profile.sh for this same workload (same passes of 4 spp -> same launches).  None if absent."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
-        try:
-            rec = json.load(open(f))
-            best = (int(rec[kernel]["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT))
-        except Exception:
-            continue
-    return best
+    scripts/gpu_profile.sh for this same workload (same pass size -> same launches).  `stale`: the recording was made
+    with other kernel / launch / tree sources than the tree holds now (sha256 stamp).  None if absent."""
+    rec, src = _newest_profile("*_pmc_traffic.json", config)
+    if rec is None or kernel not in rec:
+        return None
+    return {"bytes_per_launch": int(rec[kernel]["traffic_bytes_per_launch"]), "source": src, "rays_per_launch": rec.get("rays_per_launch"),
+            "stale": rec.get("source_sha256") != tree_sha256()}
 
 
-def recorded_valu(kernel):
+def recorded_valu(kernel, config="teapot"):
     """VALU-busy fraction of `kernel` from the committed SQ counter pass (profiles/*_pmc_valu.json, written by
-    scripts/make_valu_json.py from a `rocprofv3 --pmc` run of the same frame at 8 M-path passes).  None if absent."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json"))):
-        try:
-            rec = json.load(open(f))
-            best = {"frac": float(rec[kernel]["valu_busy_frac"]), "valu_wave_insts_per_launch": float(rec[kernel]["valu_wave_insts_per_launch"]),
-                    "source": os.path.relpath(f, ROOT)}
-        except Exception:
-            continue
-    return best
+    scripts/make_valu_json.py from a `rocprofv3 --pmc` run of the same frame).  None if absent."""
+    rec, src = _newest_profile("*_pmc_valu.json", config)
+    if rec is None or kernel not in rec:
+        return None
+    return {"frac": float(rec[kernel]["valu_busy_frac"]), "valu_wave_insts_per_launch": float(rec[kernel]["valu_wave_insts_per_launch"]),
+            "source": src, "stale": rec.get("source_sha256") != tree_sha256()}
 
 
 def parity_ray_rates(scene, desc, n_gpu=10_000_000, n_cpu=1_000_000):
@@ -91,7 +106,7 @@ def parity_ray_rates(scene, desc, n_gpu=10_000_000, n_cpu=1_000_000):
             "cpu_rays": n_cpu, "cpu_cores": threads, "id_mismatches_in_cpu_sample": int((prim != ref["prim"]).sum())}
 
 
-def cpu_baseline(desc, spp, depth, seed):
+def cpu_baseline(desc, spp, depth, seed, frame_spp):
     """The oracle (kind "port": C restatement of the reference's algorithm, faithful mode -- reference tree with loose
     boxes, no pruning, per-call matrix inversion) timed on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -102,9 +117,45 @@ def cpu_baseline(desc, spp, depth, seed):
     r = sc.render(spp=spp, max_depth=depth, seed=seed, threads=threads)
     st = r["stats"]
     return {"value": round(st.rays / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
-            "sample": "%dx%d, samples 1..%d of 1024 spp, depth %d (%.1f M rays, %.1f s)" % (
-                desc.camera.width, desc.camera.height, spp, depth, st.rays / 1e6, st.seconds),
+            "sample": "%dx%d, samples 1..%d of %d spp, depth %d (%.1f M rays, %.1f s)" % (
+                desc.camera.width, desc.camera.height, spp, frame_spp, depth, st.rays / 1e6, st.seconds),
             "samples_per_px_per_s": round(spp / st.seconds, 4)}, r["rgb"]
+
+
+CONFIGS = {
+    # name: (BASELINE.json config, default width, height, spp, depth)
+    "teapot": ("configs[1] teapot scene 1920x1080, 1024 spp, max depth 8", 1920, 1080, 1024, 8),
+    "soup": ("configs[2] synthetic 1M-triangle random soup, 1080p 256 spp", 1920, 1080, 256, 8),
+    "instanced": ("configs[3] 3 375 instanced teapots (21.3 M triangles), 4K, 4096 spp split over the ranks", 3840, 2160, 4096, 8),
+    "spheres": ("configs[4] 10 k spheres, mixed diffuse / specular, depth 16, 1080p 256 spp", 1920, 1080, 256, 16),
+}
+
+
+def build_workload(args):
+    """(scene description, host tree builder or None, text for config.workload, text for config.bvh).  The teapot frame is
+    the shipped scene.xml with the camera resized and the reference's own bvh.rs tree built on the host; the
+    synthetic configs (generators in tests/scenes.py, fixed seeds) hand no tree over -- bvh.rs degenerates
+    on unordered input -- so the library builds it."""
+    from hpt import host_bvh, scene_io
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    teapot = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "scene.xml"))
+    ref_tree = lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)
+    if args.config == "teapot":
+        teapot.camera.width, teapot.camera.height = args.width, args.height
+        return teapot, (ref_tree if args.tree == "host" else None), "teapot scene.xml %dx%d, %d spp, max depth %d, 1 frame per step" % (
+            args.width, args.height, args.spp, args.depth)
+    import scenes
+    if args.config == "soup":
+        d = scenes.soup(1_000_000, w=args.width, h=args.height)
+        what = "1 M-triangle random soup (seed 2)"
+    elif args.config == "instanced":
+        d = scenes.instanced(teapot.meshes[0], 15, w=args.width, h=args.height)
+        what = "%d teapot instances on a 15^3 lattice + floor (%.1f M triangles, seed 3)" % (len(d.nodes) - 1, (len(d.nodes) - 1) * len(teapot.meshes[0].tris) / 1e6)
+        return d, (ref_tree if args.tree == "host" else None), "%s %dx%d, %d spp, max depth %d, 1 frame per step" % (what, args.width, args.height, args.spp, args.depth)
+    else:
+        d = scenes.spheres(10_000, w=args.width, h=args.height)
+        what = "10 k spheres + floor (seed 4)"
+    return d, None, "%s %dx%d, %d spp, max depth %d, 1 frame per step" % (what, args.width, args.height, args.spp, args.depth)
 
 
 def main():
@@ -112,17 +163,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="teapot", help="BASELINE.json workload; teapot = the headline (configs[1])")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--spp-per-pass", type=int, default=0)
-    ap.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra library-SAH-tree measurement")
+    ap.add_argument("--cpu-spp", type=int, default=-1, help="samples per pixel of the CPU-baseline sample (0 = skip; default 12 for the teapot frame, 0 else)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurement with the handed-over tree left as it came")
     ap.add_argument("--tree", choices=["host", "sah"], default="host", help="host: reference bvh.rs tree handed over (drop-in); sah: library-built")
     ap.add_argument("--inflight", type=int, default=0, help="wavefront passes in flight (0 = library default, 2; 1 = one stream: every launch has the GPU to itself, "
                     "the setting of the rocprofv3 kernel-trace runs)")
     args = ap.parse_args()
+    base = CONFIGS[args.config]
+    args.width, args.height = args.width or base[1], args.height or base[2]
+    args.spp, args.depth = args.spp or base[3], args.depth or base[4]
+    if args.cpu_spp < 0:
+        args.cpu_spp = 12 if args.config == "teapot" else 0
+    default_frame = (args.width, args.height, args.depth) == base[1:3] + base[4:5] and args.tree == "host"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,17 +202,14 @@ def main():
             dist.init_process_group(backend)
 
     import hpt
-    from hpt import host_bvh, scene_io
     from hpt.dist import sample_range
 
-    desc = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "scene.xml"))
-    desc.camera.width, desc.camera.height = args.width, args.height
+    desc, tree, workload = build_workload(args)
     ctx = hpt.Context(device_index)
     if args.inflight > 0:
         ctx.set_passes_in_flight(args.inflight)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
-    tree = (lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if args.tree == "host" else None
     scene = hpt.Scene(ctx, desc, host_bvh=tree)          # scene + flattened BVH replicated on every rank's HBM
 
     npix = args.width * args.height
@@ -238,47 +293,78 @@ def main():
 
     if rank == 0:
         achieved = bytes_per_ray * rays_local / ext_s_local
-        traffic = recorded_traffic("k_extend") if (args.width, args.height, args.depth, args.tree) == (1920, 1080, 8, "host") else None
+        avg_launch_s = ext_s_local / max(ext_launches, 1)
+        rays_per_launch = rays_local / max(ext_launches, 1)
+        # physical side, from the committed counter passes of this same frame (stamped with the sources they were taken with)
+        traffic = recorded_traffic("k_extend", args.config) if default_frame else None
+        valu = recorded_valu("k_extend", args.config) if default_frame else None
+        hbm_physical = None
+        if traffic:
+            # the recording's launches may differ in size from this run's (e.g. 64-spp frame: same 66 M-path passes): scale per ray
+            per_ray = traffic["bytes_per_launch"] / traffic["rays_per_launch"] if traffic.get("rays_per_launch") else None
+            phys_bytes = per_ray * rays_per_launch if per_ray else float(traffic["bytes_per_launch"])
+            hbm_physical = {"bytes_per_launch": int(phys_bytes), "GB/s": round(phys_bytes / avg_launch_s / 1e9, 1),
+                            "frac": round(phys_bytes / avg_launch_s / HBM_PEAK, 4), "bytes_per_ray": round(phys_bytes / rays_per_launch, 1),
+                            "source": traffic["source"], "stale": traffic["stale"]}
+        limiter = None
+        if valu and hbm_physical:
+            limiter = "valu_issue" if valu["frac"] >= hbm_physical["frac"] else "hbm"
+        if args.config == "teapot":
+            bvh_text = ("reference bvh.rs tree built on host; library restructures it at flatten time (SAH re-partition + insertion rounds), tight refit"
+                        if info.trees_optimized else "reference bvh.rs tree built on host, tight refit") if args.tree == "host" else "library SAH"
+        else:
+            bvh_text = ("TLAS over instances + " if info.uses_tlas else "") + ("reference bvh.rs BLAS built on host, restructured at flatten time" if tree else "library SAH")
         line = {
-            "metric": "Mrays/sec (primary+bounce), teapot 1080p", "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "metric": "Mrays/sec (primary+bounce), %s" % ("teapot 1080p" if args.config == "teapot" else args.config), "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "teapot scene.xml %dx%d, %d spp, max depth %d, 1 frame per step" % (args.width, args.height, args.spp, args.depth),
-                       "spp_per_rank": count, "bvh": "reference bvh.rs tree built on host, tight refit" if args.tree == "host" else "library SAH",
+            "config": {"workload": workload, "baseline_config": base[0], "spp_per_rank": count, "bvh": bvh_text, "node_bytes": int(info.node_bytes),
                        "parallelism": "spp-split x%d + RCCL sum-reduce" % world, "passes_in_flight": args.inflight if args.inflight > 0 else 2},
             "samples_per_px_per_s": round(args.spp * args.steps / elapsed, 3),
             "image_mean": [round(float(v), 6) for v in image.view(-1, 3).mean(dim=0).cpu()],
             "rays_per_step": rays_total / args.steps,
             "reduce_ms_per_step": round(sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1), 4) if reduce_events else 0.0,
+            # `achieved` / `frac`: ALGORITHMIC bytes (every node and triangle a ray touches + its queue records) over the
+            # kernel's HIP-event time, priced against the HBM peak -- the figure the north_star target is stated in.  It is
+            # NOMINAL when the scene lives in the L2s (the teapot: 1.4 MB): what the HBM pins really carry is
+            # `hbm_physical`, and what limits the kernel is `limiter` (VALU issue on the teapot, see `valu`).
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None, "algorithmic_bytes_per_launch": int(bytes_per_ray * rays_local / max(ext_launches, 1)),
+                         "frac": round(achieved / HBM_PEAK, 4), "nominal": bool(info.device_bytes < 32 << 20),
+                         "traffic": hbm_physical["bytes_per_launch"] if hbm_physical else None,
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "hbm_physical": hbm_physical, "valu": valu, "limiter": limiter,
+                         "algorithmic_bytes_per_launch": int(bytes_per_ray * rays_per_launch),
                          "bytes_per_ray": round(bytes_per_ray, 1), "bvh_bytes_per_ray": round(bvh_bytes_per_ray, 1),
                          "nodes_per_ray": round(cst.nodes_visited / crays, 3), "tris_per_ray": round(cst.tris_tested / crays, 3),
+                         "inst_per_ray": round(cst.inst_tests / crays, 3),
                          "scene_bytes_in_hbm": int(info.device_bytes),
                          "bvh_fetch_frac": round(bvh_bytes_per_ray * rays_local / ext_s_local / HBM_PEAK, 4),
-                         "avg_launch_ms": round(ext_s_local / max(ext_launches, 1) * 1e3, 4), "launches": int(ext_launches),
+                         "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(ext_launches),
                          "kernel_timing": "HIP events around every launch of the same %d step(s) re-run on one stream (%.1f ms per step); the timed region keeps %s passes in flight" % (
                              args.steps, serial_elapsed / args.steps * 1e3, args.inflight if args.inflight > 0 else 2),
                          "extend_share_of_step": round(ext_s_local / serial_elapsed, 3), "shade_share_of_step": round(shade_s_local / serial_elapsed, 3),
-                         # north_star: "VALU utilisation on intersection math" -- from the recorded SQ counter pass
-                         "valu_busy": recorded_valu("k_extend") if traffic else None},
+                         "source_sha256": tree_sha256()},
         }
-        if world == 1 and args.tree == "host" and not args.no_alt:
-            # the same frame with the library's own SAH tree (hpt_scene_add_mesh(nodes = NULL)): identical hits by the
-            # deterministic tie rule, fewer node visits.  Reported beside `value`, which keeps the host-built tree.
-            alt = hpt.Scene(ctx, desc, host_bvh=None)
+        if world == 1 and tree is not None and not args.no_alt:
+            # the same frame with the handed-over tree laid out as it came (tight refit only, HPT_TREE_OPT=0 -- the round-1
+            # behaviour): identical hits by the deterministic tie rule, more box steps.  Reported beside `value`.
+            hpt.set_tree_opt(0)
+            try:
+                alt = hpt.Scene(ctx, desc, host_bvh=tree)
+            finally:
+                hpt.set_tree_opt(-1)
             with torch.cuda.stream(stream):
-                alt.render_device(accum.data_ptr(), want_stats=True, spp=min(count, 64), first_sample=first, max_depth=args.depth, seed=1)
+                alt.render_device(image.data_ptr(), want_stats=True, spp=min(count, 64), first_sample=first, max_depth=args.depth, seed=1)
                 stream.synchronize(); t1 = time.perf_counter()
-                ast = alt.render_device(accum.data_ptr(), want_stats=True, spp=count, first_sample=first, max_depth=args.depth, seed=1,
+                ast = alt.render_device(image.data_ptr(), want_stats=True, spp=count, first_sample=first, max_depth=args.depth, seed=1,
                                         spp_per_pass=args.spp_per_pass)
                 stream.synchronize(); dt = time.perf_counter() - t1
-            line["library_sah_tree"] = {"value": round((ast.rays_primary + ast.rays_bounce) / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt * 1e3, 3)}
+            line["handed_over_tree_as_is"] = {"value": round((ast.rays_primary + ast.rays_bounce) / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt * 1e3, 3)}
             alt.close()
-        if world == 1 and args.cpu_spp > 0:
+        if world == 1 and args.config == "teapot" and args.cpu_spp > 0:
             line["parity_rays"] = parity_ray_rates(scene, desc)
-            cb, cpu_img = cpu_baseline(desc, args.cpu_spp, args.depth, 1)
+        if world == 1 and args.cpu_spp > 0:
+            cb, cpu_img = cpu_baseline(desc, args.cpu_spp, args.depth, 1, args.spp)
             line["cpu_baseline"] = cb
             # sanity: the CPU sample is the first cpu_spp samples of the same frame -> must agree with the GPU's samples 1..cpu_spp
             chk = scene.render(spp=args.cpu_spp, max_depth=args.depth, seed=1)["rgb"]

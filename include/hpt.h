@@ -120,7 +120,7 @@ typedef struct {               /* what hpt_scene_commit laid out in HBM */
     int64_t n_triangles;
     uint64_t device_bytes;     /* scene data resident in HBM (render workspaces excluded) */
     int32_t node_bytes;        /* 32: 16-bit child boxes (default when the grid resolves the leaves), 64: float boxes */
-    int32_t reserved;
+    int32_t trees_optimized;   /* meshes whose tree hpt_scene_commit restructured (SAH re-partition / insertion rounds) before the layout */
 } hpt_scene_info_t;
 
 /* ---- misc ---- */
@@ -152,9 +152,10 @@ int hpt_scene_create(hpt_context* ctx, hpt_scene** out);
 void hpt_scene_destroy(hpt_scene* scene);
 /* geometry.rs:18-27 Mesh as load_obj (load.rs:282-321) builds it: 0-based index triples (ntri x 3) for position,
  * normal and texture vertex; uvw is nt x 3.  nodes/nnodes = the BVH.nodes Vec that Mesh::build_bvh
- * (geometry.rs:223, load.rs:310) produced on the host; the library validates it, refits tight boxes and flattens
- * it to the device layout.  nodes == NULL: the library builds its own (binned-SAH) tree instead -- hits do not
- * depend on the tree. */
+ * (geometry.rs:223, load.rs:310) produced on the host; the library validates it and, at hpt_scene_commit, restructures
+ * it over the same leaves (SAH re-partition + insertion rounds: bvh.rs:48-146 falls back to the index median on all
+ * but a few splits), refits tight boxes and flattens it to the device layout.  nodes == NULL: the library builds its
+ * own SAH tree instead.  Hits do not depend on the tree: images are bit-identical either way. */
 int hpt_scene_add_mesh(hpt_scene* scene, const float* verts, int32_t nv, const uint32_t* tri_idx,
                        const float* normals, int32_t nn, const uint32_t* nrm_idx,
                        const float* uvw, int32_t nt, const uint32_t* uv_idx, int32_t ntri,

@@ -79,6 +79,7 @@ struct HostMesh {
     std::vector<uint32_t> tri, ntri, ttri;
     int32_t n_tri = 0;
     HostTree tree;
+    bool host_tree = false;   // tree handed over by the host (bvh.rs:35-146 output) rather than built here
 };
 struct HostNode { int32_t parent, geom, mesh, material; float m[9], t[3]; std::vector<int32_t> children; };
 struct HostImage { std::vector<uint8_t> px; int32_t w, h; };
@@ -99,7 +100,7 @@ struct hpt_scene {
     DScene ds;
     int stack_entries = 1;
     int n_xf = 0, n_mat = 0;
-    int32_t tlas_nodes = 0, node_bytes = 64; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
+    int32_t tlas_nodes = 0, node_bytes = 64, trees_optimized = 0; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
     DevBuf w_q[2][3], w_hit, w_hit_inst, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
     struct PassBufs { DevBuf q[2][3], hit, hit_inst, radiance, counts; } x[HPT_MAX_INFLIGHT - 1];   // pass buffers of the further passes in flight
@@ -276,6 +277,7 @@ extern "C" int hpt_scene_add_mesh(hpt_scene* s, const float* verts, int32_t nv, 
     if (nodes) {
         std::string err;
         if (!tree_from_reference_nodes(nodes, nnodes, ntri, m.tree, err)) return fail(HPT_ERR_INVALID, "%s", err.c_str());
+        m.host_tree = true;
     } else {
         tree_build_sah(m.verts.data(), m.tri.data(), ntri, m.tree);
     }
@@ -357,6 +359,26 @@ static void conv_texture(const hpt_texture& t, DTexture& d) {
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) d.minv[r * 3 + c] = inv[c * 3 + r];
 }
 
+// Tree restructuring at flatten time (csrc/hpt_bvh.cpp tree_optimize).  HPT_TREE_OPT=0 keeps the handed-over topology
+// (tight refit only, the round-1 behaviour; A/B runs and the invariance tests), HPT_TREE_OPT_PASSES = insertion rounds.
+// Depth: the per-lane traversal stack lives in LDS, one KB per entry and workgroup; up to 17 interior levels the
+// instance-list kernel keeps its 5 workgroups per CU (18 entries + 12.8 KB of rings and lists = 31.5 KB; the CU hands
+// LDS out in 1 280-B granules, 128 of them, so 25 per workgroup: measured -- with 19 entries the occupancy query still
+// answered 5, four were resident and the launch took 35 % longer), so the insertion rounds may not push a tree beyond
+// that (or beyond its own depth, if it came deeper).
+#define HPT_SOFT_TREE_DEPTH 17
+#define HPT_HARD_TREE_DEPTH 38
+struct TreeOpt { int mode, passes; int32_t max_leaves_for_passes; };
+static int g_tree_opt_override = -1;
+static TreeOpt tree_opt_settings() {
+    TreeOpt o{1, 4, 1 << 18};
+    if (const char* e = getenv("HPT_TREE_OPT")) o.mode = atoi(e) != 0;
+    if (const char* e = getenv("HPT_TREE_OPT_PASSES")) o.passes = std::min(std::max(atoi(e), 0), 64);
+    if (const char* e = getenv("HPT_TREE_OPT_MAX_LEAVES")) o.max_leaves_for_passes = std::max(atoi(e), 0);
+    if (g_tree_opt_override >= 0) o.mode = g_tree_opt_override;
+    return o;
+}
+
 // main.rs:43-53
 static void camera_frame(const hpt_camera& c, DCamera& f) {
     const float PI = 3.14159265358979323846f;
@@ -385,9 +407,25 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     std::vector<TreeSlice> trees;   // every tree in nodes[] (one per mesh, then the TLAS) with its Node32 grid
     s->h_meshes.clear();
     s->stack_entries = 1;
+    const TreeOpt topt = tree_opt_settings();
+    s->trees_optimized = 0;
     for (HostMesh& m : s->meshes) {
         FlatMesh fm; std::string err;
-        if (!flatten_mesh(m.tree, m.verts.data(), m.tri.data(), m.normals.data(), m.ntri.data(), m.uvw.data(), m.ttri.data(), m.n_tri, fm, err))
+        // The handed-over tree is restructured before it is laid out (hits do not depend on the tree): SAH re-partition
+        // of the host's leaves + insertion rounds; a library-built tree gets the insertion rounds alone.
+        HostTree opt_tree; const HostTree* use = &m.tree;
+        if (topt.mode != 0 && m.n_tri >= 4) {
+            std::vector<float> leaf((size_t)m.n_tri * 6);
+            for (int32_t f = 0; f < m.n_tri; ++f)
+                for (int k = 0; k < 3; ++k) {
+                    const float a = m.verts[3 * (size_t)m.tri[3 * (size_t)f] + k], b = m.verts[3 * (size_t)m.tri[3 * (size_t)f + 1] + k], c = m.verts[3 * (size_t)m.tri[3 * (size_t)f + 2] + k];
+                    leaf[6 * (size_t)f + k] = std::min(a, std::min(b, c)); leaf[6 * (size_t)f + 3 + k] = std::max(a, std::max(b, c));
+                }
+            opt_tree = m.tree;
+            const int passes = m.n_tri <= topt.max_leaves_for_passes ? topt.passes : 0;
+            if (tree_optimize(opt_tree, leaf.data(), m.n_tri, HPT_HARD_TREE_DEPTH, HPT_SOFT_TREE_DEPTH, passes, m.host_tree)) { use = &opt_tree; s->trees_optimized++; }
+        }
+        if (!flatten_mesh(*use, m.verts.data(), m.tri.data(), m.normals.data(), m.ntri.data(), m.uvw.data(), m.ttri.data(), m.n_tri, fm, err))
             return fail(HPT_ERR_INVALID, "%s", err.c_str());
         const int64_t node_base = (int64_t)(nodes.size() / 16), tri_base = (int64_t)(tris.size() / 12);
         if (node_base + fm.n_interior >= (1ll << 31) || tri_base + m.n_tri >= (1ll << 31)) return fail(HPT_ERR_LIMIT, "scene: more than 2^31 nodes/triangles");
@@ -495,6 +533,8 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         }
         HostTree tt; FlatMesh ft; std::string err;
         tree_build_sah_boxes(wb.data(), (int32_t)inst.size(), tt);
+        if (topt.mode != 0 && (int32_t)inst.size() <= topt.max_leaves_for_passes)
+            (void)tree_optimize(tt, wb.data(), (int32_t)inst.size(), 24, 24, topt.passes, false);
         if (!flatten_tree(tt, wb.data(), (int32_t)inst.size(), ft, err)) return fail(HPT_ERR_INVALID, "%s", err.c_str());
         const int64_t node_base = (int64_t)(nodes.size() / 16);
         if (node_base + ft.n_interior >= (1ll << 31)) return fail(HPT_ERR_LIMIT, "scene: more than 2^31 nodes");
@@ -1049,12 +1089,13 @@ extern "C" int hpt_scene_info(hpt_scene* s, hpt_scene_info_t* out) {
     out->n_meshes = (int32_t)s->meshes.size(); out->n_materials = s->n_mat;
     out->n_nodes = s->ds.n_nodes; out->n_triangles = s->n_tris_total; out->tlas_nodes = s->tlas_nodes;
     out->uses_tlas = s->ds.use_tlas; out->stack_entries = s->stack_entries; out->device_bytes = s->device_bytes;
-    out->node_bytes = s->node_bytes;
+    out->node_bytes = s->node_bytes; out->trees_optimized = s->trees_optimized;
     return HPT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ tuning hooks
 // Not part of include/hpt.h: used by scripts/gpu_time.py for interleaved A/B runs inside one process.
+extern "C" void hpt_debug_set_tree_opt(int mode) { g_tree_opt_override = mode; }      // -1: environment / default; applies to later commits
 extern "C" void hpt_debug_set_refill(int lanes) { hptk_set_refill(lanes); }
 extern "C" void hpt_debug_set_overlap(hpt_context* ctx, int n) { if (ctx) ctx->overlap = std::min(std::max(n, 1), HPT_MAX_INFLIGHT); }
 extern "C" void hpt_debug_set_extend_blocks(hpt_context* ctx, int per_cu) { if (ctx && per_cu >= 0 && per_cu <= 16) ctx->extend_per_cu = per_cu; }

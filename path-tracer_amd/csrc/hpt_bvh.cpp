@@ -73,6 +73,7 @@ void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, H
 namespace {
 struct SahBuilder {
     static constexpr int NB = 16;
+    static constexpr int32_t SWEEP_MAX = 4096;
     const std::vector<Box>& boxes; const std::vector<float>& cent; std::vector<int32_t>& ids; HostTree& out;
     struct Job { int32_t node, lo, hi; };
 
@@ -87,6 +88,30 @@ struct SahBuilder {
         if (ext[2] > ext[axis]) axis = 2;
         int32_t mid = lo + n / 2;
         if (!(ext[axis] > 0.0f)) return mid;
+        if (n <= SWEEP_MAX) {      // exact sweep: every split position of every axis
+            std::vector<int32_t> tmp(ids.begin() + lo, ids.begin() + hi), best_order;
+            std::vector<float> right_area((size_t)n);
+            float best_cost = std::numeric_limits<float>::infinity(); int32_t best_i = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!(ext[ax] > 0.0f)) continue;
+                std::sort(tmp.begin(), tmp.end(), [&](int32_t a, int32_t b) {
+                    const float ca = cent[3 * (size_t)a + ax], cb2 = cent[3 * (size_t)b + ax];
+                    return ca != cb2 ? ca < cb2 : a < b;
+                });
+                Box acc; acc.reset();
+                for (int32_t i = n - 1; i > 0; --i) { acc.grow(boxes[tmp[i]]); right_area[i] = acc.half_area(); }
+                acc.reset();
+                bool improved = false;
+                for (int32_t i = 1; i < n; ++i) {
+                    acc.grow(boxes[tmp[i - 1]]);
+                    const float cost = acc.half_area() * (float)i + right_area[i] * (float)(n - i);
+                    if (cost < best_cost) { best_cost = cost; best_i = i; improved = true; }
+                }
+                if (improved) best_order = tmp;
+            }
+            if (best_i > 0) { std::copy(best_order.begin(), best_order.end(), ids.begin() + lo); mid = lo + best_i; }
+            return mid;
+        }
         int best_axis = -1, best_split = -1; float best_cost = std::numeric_limits<float>::infinity();
         for (int ax = 0; ax < 3; ++ax) {
             if (!(ext[ax] > 0.0f)) continue;
@@ -169,6 +194,164 @@ void tree_build_sah_boxes(const float* leaf_boxes, int32_t ntri, HostTree& out) 
     for (int t = 0; t < nthreads; ++t)
         pool.emplace_back([&]() { for (size_t k; (k = next.fetch_add(1)) < tasks.size();) B.run(tasks[k]); });
     for (std::thread& th : pool) th.join();
+}
+
+// ------------------------------------------------------------------------------------------------ tree optimiser
+// The tree the host hands over is the one bvh.rs:48-146 builds: on the shipped teapot only 69 of its 6 319 splits are
+// real partitions (the others fall back to the index median), so it costs 6.5 box steps per ray where a
+// surface-area-heuristic tree over the same leaves costs 3.  Hits do not depend on the tree (closest t, ties to the
+// lower triangle index), so hpt_scene_commit restructures what it flattens: (1) a top-down SAH re-partition of the
+// host's leaves -- exact sweep over all three axes for ranges up to 4 096 leaves, binned above -- and (2) rounds of
+// insertion-based optimisation (remove a subtree, re-insert it where the surface area of the tree grows least,
+// branch-and-bound search; Bittner, Hapala, Havran 2013).  bvh.rs stays the builder on the host; this repairs its
+// output the way the tight refit already repaired its boxes.
+namespace {
+inline Box leaf_box(const float* leaf_boxes, int32_t p) {
+    Box b; const float* q = leaf_boxes + 6 * (size_t)p;
+    for (int k = 0; k < 3; ++k) { b.mn[k] = q[k]; b.mx[k] = q[3 + k]; }
+    return b;
+}
+inline Box box_union(const Box& a, const Box& b) { Box r = a; r.grow(b); return r; }
+
+struct Reinserter {
+    HostTree& t; std::vector<int32_t> parent, ih; std::vector<Box> box;      // ih: interior levels in the subtree (leaf 0)
+    int32_t depth_limit = 1 << 30;
+    Reinserter(HostTree& tree, const float* leaf_boxes) : t(tree) {
+        const int32_t nn = (int32_t)t.left.size();
+        parent.assign((size_t)nn, -1); ih.assign((size_t)nn, 0); box.resize((size_t)nn);
+        std::vector<int32_t> order; order.reserve((size_t)nn);
+        std::vector<int32_t> st{t.root};
+        while (!st.empty()) {
+            const int32_t i = st.back(); st.pop_back(); order.push_back(i);
+            if (t.prim[i] < 0) { parent[t.left[i]] = i; parent[t.right[i]] = i; st.push_back(t.left[i]); st.push_back(t.right[i]); }
+        }
+        for (size_t k = order.size(); k-- > 0;) {
+            const int32_t i = order[k];
+            box[i] = t.prim[i] >= 0 ? leaf_box(leaf_boxes, t.prim[i]) : box_union(box[t.left[i]], box[t.right[i]]);
+            ih[i] = t.prim[i] >= 0 ? 0 : 1 + std::max(ih[t.left[i]], ih[t.right[i]]);
+        }
+    }
+    void refit_up(int32_t i) {
+        for (; i >= 0; i = parent[i]) {
+            const Box nb = box_union(box[t.left[i]], box[t.right[i]]);
+            const int32_t nh = 1 + std::max(ih[t.left[i]], ih[t.right[i]]);
+            if (nh == ih[i] && std::memcmp(&nb, &box[i], sizeof nb) == 0) break;
+            box[i] = nb; ih[i] = nh;
+        }
+    }
+    double cost() const {
+        double c = 0.0;
+        for (size_t i = 0; i < box.size(); ++i) if (t.prim[i] < 0) c += box[i].half_area();
+        return c;
+    }
+    struct Cand { float induced; int32_t node, level; };
+    // moves subtree n to the position where the tree's surface area grows least; returns true if the tree changed
+    bool reinsert(int32_t n, std::vector<Cand>& heap) {
+        const int32_t p = parent[n];
+        if (p < 0 || parent[p] < 0) return false;      // the root and its children stay (the root record is the entry point)
+        const int32_t g = parent[p], s = t.left[p] == n ? t.right[p] : t.left[p];
+        const float before = box[p].half_area();
+        // unlink p: s takes its place under g
+        (t.left[g] == p ? t.left[g] : t.right[g]) = s; parent[s] = g;
+        refit_up(g);
+        const Box nb = box[n]; const float na = nb.half_area();
+        // branch and bound over insertion positions x: cost = area(x U n) + sum over x's ancestors of their growth
+        float best = std::numeric_limits<float>::infinity(); int32_t best_x = -1;
+        heap.clear(); heap.push_back({0.0f, t.root, 1});
+        auto cmp = [](const Cand& a, const Cand& b) { return a.induced > b.induced; };
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            const Cand c = heap.back(); heap.pop_back();
+            if (c.induced + na >= best) break;
+            const float direct = box_union(box[c.node], nb).half_area();
+            const float total = c.induced + direct;
+            // the new parent takes x's level; x and n go one level down: deepest interior level below = level + max(ih)
+            if (total < best && c.level + std::max(ih[c.node], ih[n]) <= depth_limit) { best = total; best_x = c.node; }
+            const float child_induced = total - box[c.node].half_area();
+            if (t.prim[c.node] < 0 && child_induced + na < best) {
+                heap.push_back({child_induced, t.left[c.node], c.level + 1}); std::push_heap(heap.begin(), heap.end(), cmp);
+                heap.push_back({child_induced, t.right[c.node], c.level + 1}); std::push_heap(heap.begin(), heap.end(), cmp);
+            }
+        }
+        int32_t x = best_x;
+        // putting it back where it was costs `before` more than the unlinked tree: only move for a strict gain
+        if (x < 0 || !(best < before) || x == s) x = s;
+        const int32_t xp = parent[x];
+        t.left[p] = x; t.right[p] = n; parent[x] = p; parent[n] = p; parent[p] = xp;
+        if (xp < 0) t.root = p; else (t.left[xp] == x ? t.left[xp] : t.right[xp]) = p;
+        box[p] = box_union(box[x], nb); ih[p] = 1 + std::max(ih[x], ih[n]);
+        if (xp >= 0) refit_up(xp);
+        return x != s;
+    }
+    int32_t depth() const {      // deepest interior level, root = 1 (what flatten_tree reports as max_depth)
+        int32_t best = 0;
+        std::vector<std::pair<int32_t, int32_t>> st{{t.root, 1}};
+        while (!st.empty()) {
+            const auto [i, d] = st.back(); st.pop_back();
+            if (t.prim[i] >= 0) continue;
+            best = std::max(best, d);
+            st.push_back({t.left[i], d + 1}); st.push_back({t.right[i], d + 1});
+        }
+        return best;
+    }
+};
+}  // namespace
+
+double tree_sah_cost(const HostTree& tree, const float* leaf_boxes) {
+    HostTree copy = tree;
+    Reinserter R(copy, leaf_boxes);
+    const double root = R.box[copy.root].half_area();
+    return root > 0.0 ? R.cost() / root : 0.0;
+}
+
+int32_t tree_interior_depth(const HostTree& tree) {
+    int32_t best = 0;
+    std::vector<std::pair<int32_t, int32_t>> st{{tree.root, 1}};
+    while (!st.empty()) {
+        const auto [i, d] = st.back(); st.pop_back();
+        if (tree.prim[i] >= 0) continue;
+        best = std::max(best, d);
+        st.push_back({tree.left[i], d + 1}); st.push_back({tree.right[i], d + 1});
+    }
+    return best;
+}
+
+bool tree_optimize(HostTree& tree, const float* leaf_boxes, int32_t nleaf, int32_t hard_depth, int32_t soft_depth, int passes, bool rebuild) {
+    if (nleaf < 4) return false;
+    bool changed = false;
+    if (rebuild) {
+        HostTree rebuilt;
+        tree_build_sah_boxes(leaf_boxes, nleaf, rebuilt);
+        if (tree_interior_depth(rebuilt) > hard_depth) return false;      // (median fallbacks keep it near log2 n)
+        tree = rebuilt; changed = true;
+    }
+    if (passes <= 0) return changed;
+    const int32_t depth_in = tree_interior_depth(tree);
+    HostTree work = tree;
+    Reinserter R(work, leaf_boxes);
+    R.depth_limit = std::min(hard_depth, std::max(soft_depth, depth_in));
+    const int32_t nn = (int32_t)work.left.size();
+    std::vector<int32_t> order((size_t)nn);
+    std::vector<Reinserter::Cand> heap;
+    double prev = R.cost();
+    const double first = prev;
+    for (int pass = 0; pass < passes; ++pass) {
+        for (int32_t i = 0; i < nn; ++i) order[i] = i;
+        // largest boxes first: they are the ones whose misplacement costs most
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            const float aa = R.box[a].half_area(), ab = R.box[b].half_area();
+            return aa != ab ? aa > ab : a < b;
+        });
+        for (int32_t n : order) R.reinsert(n, heap);
+        const double now = R.cost();
+        if (!(now < prev * 0.999)) { prev = std::min(prev, now); break; }
+        prev = now;
+    }
+    // a deeper tree needs more traversal-stack entries (LDS per lane): beyond soft_depth they cost resident workgroups,
+    // which no few per cent of surface area win back -- keep the input then
+    const int32_t depth_out = R.depth();
+    if (prev < first && depth_out <= hard_depth && depth_out <= std::max(soft_depth, depth_in)) { tree = work; changed = true; }
+    return changed;
 }
 
 bool flatten_tree(const HostTree& tree, const float* leaf_boxes, int32_t nleaf, FlatMesh& out, std::string& err) {

@@ -27,6 +27,14 @@ bool tree_from_reference_nodes(const hpt_bvh_node* nodes, int32_t nnodes, int32_
 void tree_build_sah(const float* verts, const uint32_t* tri_idx, int32_t ntri, HostTree& out);
 // same over arbitrary leaf boxes (n x 6: min, max) -- the TLAS over instance world boxes uses this
 void tree_build_sah_boxes(const float* leaf_boxes, int32_t n, HostTree& out);
+// Restructures a tree over the same leaves for fewer box steps per ray: (rebuild) top-down SAH re-partition, then
+// `passes` rounds of insertion-based optimisation.  A result deeper than hard_depth (the traversal stack limit) is
+// never produced; the insertion rounds are dropped when they leave the tree deeper than max(soft_depth, depth before).
+// Returns whether the tree changed.  Hits do not depend on the tree, so this never changes a result.
+bool tree_optimize(HostTree& tree, const float* leaf_boxes, int32_t nleaf, int32_t hard_depth, int32_t soft_depth, int passes, bool rebuild);
+// sum of the interior nodes' surface areas / the root's: expected box steps of a random ray through the root box
+double tree_sah_cost(const HostTree& tree, const float* leaf_boxes);
+int32_t tree_interior_depth(const HostTree& tree);
 // tight refit + breadth-first renumbering + Node64 packing of any tree over leaf boxes; leaf refs are ~prim
 bool flatten_tree(const HostTree& tree, const float* leaf_boxes, int32_t nleaf, FlatMesh& out, std::string& err);
 // Tight refit + breadth-first renumbering + packing.  Child refs are LOCAL to the mesh; the caller rebases them.

@@ -1341,6 +1341,9 @@ template <typename K>
 static int resident_blocks(K k, size_t lds) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, HPT_BLOCK, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    // the query rounds LDS less coarsely than the CU allocates it (128 granules of 1 280 B): 32 528 B per workgroup was
+    // reported as 5 resident, 4 were -- and a persistent grid larger than what is resident runs 35 % longer
+    if (lds > 0) n = std::min<int>(n, (int)(128 / ((lds + 1279) / 1280)));
     return n;
 }
 // The instance-list kernel takes its input through the work counter when the scene's trees are big (rays cost tens of

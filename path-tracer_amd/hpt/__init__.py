@@ -61,7 +61,7 @@ class TraceStats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_instances", C.c_int32), ("n_mesh_instances", C.c_int32), ("n_meshes", C.c_int32), ("n_materials", C.c_int32),
                 ("n_nodes", C.c_int32), ("tlas_nodes", C.c_int32), ("uses_tlas", C.c_int32), ("stack_entries", C.c_int32),
-                ("n_triangles", C.c_int64), ("device_bytes", C.c_uint64), ("node_bytes", C.c_int32), ("reserved", C.c_int32)]
+                ("n_triangles", C.c_int64), ("device_bytes", C.c_uint64), ("node_bytes", C.c_int32), ("trees_optimized", C.c_int32)]
 
 
 # every symbol include/hpt.h declares (tests check that the library exports all of them)
@@ -185,6 +185,12 @@ def fill_camera(dst, c):
 
 def device_count():
     return lib.hpt_device_count()
+
+
+def set_tree_opt(mode):
+    """tuning / test hook (not in include/hpt.h): 0 keeps the handed-over tree topology at later commits, 1 restructures
+    it (default), -1 back to the environment (HPT_TREE_OPT)"""
+    lib.hpt_debug_set_tree_opt(int(mode))
 
 
 class Context:

@@ -70,7 +70,7 @@ pub struct hpt_scene_info_t {
     pub n_instances: i32, pub n_mesh_instances: i32, pub n_meshes: i32, pub n_materials: i32,
     pub n_nodes: i32, pub tlas_nodes: i32, pub uses_tlas: i32, pub stack_entries: i32,
     pub n_triangles: i64, pub device_bytes: u64,
-    pub node_bytes: i32, pub reserved: i32,
+    pub node_bytes: i32, pub trees_optimized: i32,
 }
 
 extern "C" {

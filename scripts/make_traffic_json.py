@@ -1,6 +1,8 @@
 """profiles/<tag>_pmc_traffic.json from the two PMC summaries scripts/gpu_profile.sh wrote (FETCH_SIZE, WRITE_SIZE):
    python3 scripts/make_traffic_json.py gpurun_out/prof_<x> profiles/<tag>"""
-import json, re, sys
+import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_stamp import source_sha256, STAMPED
 src, dst = sys.argv[1], sys.argv[2]
 
 
@@ -17,7 +19,8 @@ b = json.load(open(src + "/pmc_fetch.json"))
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --inflight 1 --spp 64 --steps 1 --warmup 0 --cpu-spp 0 --no-alt",
        "workload": b["config"]["workload"],
        "unit": "KB per launch as rocprofv3 reports; bytes = KB*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B reads at 64 B)",
-       "rays_per_launch": b["rays_per_step"] / b["roofline"]["launches"]}
+       "rays_per_launch": b["rays_per_step"] / b["roofline"]["launches"],
+       "source_sha256": source_sha256(), "source_files": list(STAMPED)}
 for key, name in (("k_extend", "void k_extend<false, false"), ("k_shade", "void k_shade<true>")):
     f, n = grab(src + "/pmc_fetch_summary.txt", name, "FETCH_SIZE")
     w, _ = grab(src + "/pmc_write_summary.txt", name, "WRITE_SIZE")

@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <algorithm>
 #include "hpt_bvh.h"
 // builds a valid pre-order tree over n triangles, mutates it, and pushes it through validation + flatten
 static int build(std::vector<hpt_bvh_node>& out, int lo, int hi, std::mt19937& rng) {
@@ -44,6 +45,38 @@ int main() {
         if (!flatten_mesh(t, verts.data(), tri.data(), a.data(), z.data(), a.data(), z.data(), n, fm, err)) { std::printf("sah flatten failed: %s\n", err.c_str()); return 1; }
         std::vector<float> nanv(n * 9, NAN);
         HostTree t2; tree_build_sah(nanv.data(), tri.data(), n, t2);
+    }
+    // tree optimiser: random trees over random boxes -> still a tree over exactly the same leaves, never costlier,
+    // never deeper than the limits it was given
+    for (int it = 0; it < 300; ++it) {
+        int n = 4 + (int)(rng() % 400);
+        std::vector<float> lb(n * 6);
+        for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) {
+            float c0 = (float)(rng() % 1000) / 10.0f, e = (it % 7 == 0) ? 0.0f : (float)(rng() % 100) / 20.0f;
+            lb[6 * i + k] = c0; lb[6 * i + 3 + k] = c0 + e;
+        }
+        std::vector<hpt_bvh_node> nodes; build(nodes, 0, n, rng);
+        HostTree t; std::string err;
+        if (!tree_from_reference_nodes(nodes.data(), (int)nodes.size(), n, t, err)) { std::printf("valid tree rejected: %s\n", err.c_str()); return 1; }
+        const double before = tree_sah_cost(t, lb.data());
+        const int soft = 4 + (int)(rng() % 30), din = tree_interior_depth(t);
+        HostTree o = t;
+        const bool rebuild = rng() % 2;
+        tree_optimize(o, lb.data(), n, 38, soft, (int)(rng() % 4), rebuild);
+        std::vector<int> seen(n, 0); int leaves = 0, interior = 0;
+        std::vector<int> st{o.root};
+        while (!st.empty()) {
+            int i = st.back(); st.pop_back();
+            if (o.prim[i] >= 0) { seen[o.prim[i]]++; ++leaves; } else { ++interior; st.push_back(o.left[i]); st.push_back(o.right[i]); }
+        }
+        for (int i = 0; i < n; ++i) if (seen[i] != 1) { std::printf("optimiser lost or duplicated leaf %d\n", i); return 1; }
+        if (leaves != n || interior != n - 1) { std::printf("optimiser: not a binary tree over the leaves\n"); return 1; }
+        const double after = tree_sah_cost(o, lb.data());
+        if (after > before * 1.0001 && !rebuild) { std::printf("insertion rounds raised the cost %g -> %g\n", before, after); return 1; }
+        const int dout = tree_interior_depth(o);
+        if (dout > 38 || (!rebuild && dout > std::max(soft, din))) { std::printf("optimiser depth %d (in %d, soft %d)\n", dout, din, soft); return 1; }
+        FlatMesh fm;
+        if (!flatten_tree(o, lb.data(), n, fm, err)) { std::printf("flatten after optimise: %s\n", err.c_str()); return 1; }
     }
     std::printf("accepted %d rejected %d\n", ok, rej);
     return 0;

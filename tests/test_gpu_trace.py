@@ -67,6 +67,33 @@ def test_library_built_tree_gives_same_hits(ctx, desc, oscene):
     sc.close()
 
 
+def test_tree_optimizer_changes_no_result(ctx, desc, oscene):
+    """hpt_scene_commit restructures the handed-over bvh.rs tree (SAH re-partition + insertion rounds, csrc/hpt_bvh.cpp
+    tree_optimize).  1 M parity rays and a 64x48x16 image must be bit-identical with and without it; it must cut the box
+    steps per ray, and stay inside the traversal-stack budget."""
+    import hpt
+    from conftest import resized
+    org, dirs = R.parity_rays(oscene.meshes[0].box(), 1_000_000, seed=77)
+    out = {}
+    try:
+        for mode in (0, 1):
+            hpt.set_tree_opt(mode)
+            sc = hpt.Scene(ctx, resized(desc, 64, 48), host_bvh=host_tree)
+            info = sc.info()
+            assert info.trees_optimized == mode and info.stack_entries <= 20
+            out[mode] = (sc.trace_rays(0, org, dirs), sc.render(spp=16, max_depth=8, seed=3), sc.render_samples(spp=2, max_depth=8, seed=5))
+            sc.close()
+    finally:
+        hpt.set_tree_opt(-1)
+    for k in ("prim", "t", "u", "v", "side"):
+        np.testing.assert_array_equal(out[0][0][k], out[1][0][k])
+    np.testing.assert_array_equal(out[0][1]["rgb"], out[1][1]["rgb"])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert out[0][1]["stats"].rays_bounce == out[1][1]["stats"].rays_bounce
+    assert out[1][0]["stats"].nodes_visited < 0.6 * out[0][0]["stats"].nodes_visited
+    compare(out[1][0], oscene.meshes[0].intersect(org, dirs))
+
+
 def test_far_from_the_origin(ctx, olib, desc, monkeypatch):
     """Box culling stays conservative when |origin| >> |t|: the teapot moved far away, rays starting next to it --
     b = fl(o/d) then carries an absolute error far above any relative slack on t (the kernels before the per-axis bound
