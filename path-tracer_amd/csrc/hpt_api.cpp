@@ -71,7 +71,9 @@ struct hpt_context {
     int max_blocks = 2048;
     int extend_blocks = 1024;   // persistent grid of the test-entry traversal kernels
     int extend_per_cu = 0;      // workgroups per CU of k_extend; 0 = by kernel variant and LDS need (extend_grid)
-    std::vector<hipEvent_t> events;   // pool for HPT_RENDER_TIME_KERNELS
+    std::vector<hipEvent_t> events;   // pool for HPT_RENDER_TIME_KERNELS and the trace entry's kernel timing
+    int live_scenes = 0;              // scenes created on this context and not yet destroyed
+    bool destroy_pending = false;     // hpt_context_destroy was called while scenes were live: freed with the last scene
 };
 
 struct HostMesh {
@@ -100,6 +102,8 @@ struct hpt_scene {
     DScene ds;
     int stack_entries = 1;
     int n_xf = 0, n_mat = 0;
+    HptkPlan plan;              // launch configuration of this scene's kernels (hpt_scene_commit)
+    int shade_grid = 0;         // k_shade workgroups per launch
     int32_t tlas_nodes = 0, node_bytes = 64, trees_optimized = 0; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
     DevBuf w_q[2][3], w_hit, w_hit_inst, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
@@ -169,6 +173,8 @@ extern "C" int hpt_tonemap_rgba8(const float* rgb, uint32_t n, uint8_t* rgba) { 
     return HPT_OK;
 }
 
+static int context_init(hpt_context* c);
+static void context_free(hpt_context* c);
 extern "C" int hpt_context_create(int device, hpt_context** out) {
     if (!out) return fail(HPT_ERR_INVALID, "hpt_context_create: out is null");
     *out = nullptr;
@@ -179,6 +185,13 @@ extern "C" int hpt_context_create(int device, hpt_context** out) {
     HIPCHK(hipSetDevice(device));
     hpt_context* c = new hpt_context();
     c->device = device;
+    const int rc = context_init(c);
+    if (rc != HPT_OK) { context_free(c); return rc; }      // (streams and events created so far go with it)
+    *out = c;
+    return HPT_OK;
+}
+static int context_init(hpt_context* c) {
+    const int device = c->device;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -192,11 +205,17 @@ extern "C" int hpt_context_create(int device, hpt_context** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (hipEvent_t& e : c->ev_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->stream = c->own_stream;
-    *out = c;
     return HPT_OK;
 }
+// Scenes keep a pointer to their context (device, streams): destroying the context first would leave them dangling
+// -- Python's __del__ order at interpreter exit does exactly that.  So a context with live scenes is only marked; the
+// last hpt_scene_destroy frees it.
 extern "C" void hpt_context_destroy(hpt_context* c) {
     if (!c) return;
+    if (c->live_scenes > 0) { c->destroy_pending = true; return; }
+    context_free(c);
+}
+static void context_free(hpt_context* c) {
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -225,8 +244,9 @@ extern "C" int hpt_context_synchronize(hpt_context* c) {
 
 extern "C" int hpt_scene_create(hpt_context* ctx, hpt_scene** out) {
     if (!ctx || !out) return fail(HPT_ERR_INVALID, "hpt_scene_create: null argument");
+    if (ctx->destroy_pending) return fail(HPT_ERR_STATE, "hpt_scene_create: the context has been destroyed");
     hpt_scene* s = new hpt_scene();
-    s->ctx = ctx;
+    s->ctx = ctx; ctx->live_scenes++;
     identity_tex(s->background); identity_tex(s->environment);
     const hpt_camera cam = {{0, 0, 0}, {0, 0, -1}, {0, 1, 0}, 40.0f, 800, 600, 1.0f, 0.0f};   // scene.rs:107-120
     s->camera = cam;
@@ -250,7 +270,9 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
         for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) x.q[a][k].release();
     }
     for (DevBuf& b : s->t_misc) b.release();
+    hpt_context* ctx = s->ctx;
     delete s;
+    if (--ctx->live_scenes == 0 && ctx->destroy_pending) context_free(ctx);
 }
 
 extern "C" int hpt_scene_add_mesh(hpt_scene* s, const float* verts, int32_t nv, const uint32_t* tri_idx,
@@ -288,6 +310,10 @@ extern "C" int hpt_scene_add_mesh(hpt_scene* s, const float* verts, int32_t nv, 
 }
 extern "C" int hpt_scene_add_image(hpt_scene* s, const uint8_t* rgb8, int32_t w, int32_t h, int32_t* image_id) {
     if (!s || w < 0 || h < 0 || (!rgb8 && (int64_t)w * h > 0)) return fail(HPT_ERR_INVALID, "hpt_scene_add_image: bad argument");
+    // scene.rs:330 indexes x % width, y % height: an image with exactly one zero dimension panics there (division by zero);
+    // 0 x 0 is the reference's "no data" image (scene.rs:323 returns black)
+    if ((w == 0) != (h == 0)) return fail(HPT_ERR_INVALID, "hpt_scene_add_image: %d x %d image (one dimension is zero)", w, h);
+    if ((int64_t)w * h > (1ll << 28)) return fail(HPT_ERR_LIMIT, "hpt_scene_add_image: more than 2^28 pixels");
     HostImage im; im.w = w; im.h = h;
     im.px.assign(rgb8, rgb8 + (size_t)w * (size_t)h * 3);
     s->images.push_back(std::move(im));
@@ -616,6 +642,11 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     d.n_mesh_instances = (int32_t)meshinst.size(); d.n_nodes = (int32_t)(nodes.size() / 16);
     conv_texture(s->background, d.background); conv_texture(s->environment, d.environment);
     camera_frame(s->camera, d.cam);
+    // launch configuration: depends on the committed scene only (occupancy queries, LDS layout) -- not per launch
+    hptk_plan(s->stack_entries, d, s->n_xf, s->n_mat, &s->plan);
+    // k_shade: two rounds of exactly the resident workgroups (5/CU -> 10/CU measured best: 8/CU +3 %, 4/CU +8 %)
+    s->shade_grid = s->plan.shade_per_cu > 0 ? ctx->num_cus * s->plan.shade_per_cu * 2 : ctx->max_blocks;
+    if (const char* e = getenv("HPT_SHADE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) s->shade_grid = ctx->num_cus * v; }
     s->committed = true;
     return HPT_OK;
 }
@@ -643,7 +674,9 @@ extern "C" int hpt_trace_rays_device(hpt_scene* s, int32_t mesh_id, int64_t n, c
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (stats) {
         HIPCHK(hipMemsetAsync(d_stat, 0, 8 * sizeof(unsigned long long), st));
-        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        // two events of the context's pool (created once, destroyed with the context: nothing to leak on an error return)
+        while (ctx->events.size() < 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->events.push_back(e); }
+        e0 = ctx->events[0]; e1 = ctx->events[1];
         HIPCHK(hipEventRecord(e0, st));
     }
     hptk_trace_rays(st, ctx->extend_blocks, s->ds, s->h_meshes[mesh_id], n, (const float4*)org4, (const float4*)dir4, (float4*)hit4, (uint8_t*)side_out,
@@ -654,7 +687,6 @@ extern "C" int hpt_trace_rays_device(hpt_scene* s, int32_t mesh_id, int64_t n, c
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0.0f;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         unsigned long long h[8];
         HIPCHK(hipMemcpy(h, d_stat, sizeof h, hipMemcpyDeviceToHost));
         stats->rays = (uint64_t)n; stats->nodes_visited = h[1]; stats->tris_tested = h[2];
@@ -791,11 +823,9 @@ static int extend_grid(const hpt_scene* s, int inflight) {
     const hpt_context* ctx = s->ctx;
     int per_cu = ctx->extend_per_cu;
     if (per_cu <= 0) {
-        per_cu = hptk_extend_blocks_per_cu(s->stack_entries, s->ds);
-        if (per_cu <= 0) {      // query failed: register budget of the kernels (hpt_kernels.hip) and LDS fit
-            const size_t lds = hptk_extend_lds_bytes(s->stack_entries, s->ds);
-            per_cu = std::min(4, (int)((160u * 1024u) / std::max<size_t>(lds, 1)));
-        }
+        per_cu = s->plan.extend_per_cu;
+        if (per_cu <= 0)      // query failed: register budget of the kernels (hpt_kernels.hip) and LDS fit
+            per_cu = std::min(4, (int)((160u * 1024u) / std::max<size_t>(s->plan.extend_lds, 1)));
         // (instance-list kernel only; the two-level kernel: 10 k spheres +1 %, instanced teapots -2.5 %)
         if (inflight > 1 && !s->ds.use_tlas && per_cu > ctx->extend_spare) per_cu -= ctx->extend_spare;
     }
@@ -813,14 +843,10 @@ static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool c
     CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps); CHK(ev.end(st));
     const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
     const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
-    // k_shade: two rounds of exactly the resident workgroups (5/CU -> 10/CU measured best: 8/CU +3 %, 4/CU +8 %)
-    int shade_grid = ctx->max_blocks;
-    { const int r = hptk_shade_blocks_per_cu(s->ds, s->n_xf, s->n_mat); if (r > 0) shade_grid = ctx->num_cus * r * 2; }
-    if (const char* e = getenv("HPT_SHADE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) shade_grid = ctx->num_cus * v; }
-    const int sblocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)shade_grid);
+    const int sblocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)s->shade_grid);
     for (int depth = 0; depth <= ps.max_depth; ++depth) {
-        CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->stack_entries, s->ds, ps, depth, counters); CHK(ev.end(st));
-        CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->ds, ps, depth, s->n_xf, s->n_mat); CHK(ev.end(st));
+        CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st));
+        CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->plan, s->ds, ps, depth, s->n_xf, s->n_mat); CHK(ev.end(st));
     }
     if (after) HIPCHK(hipStreamWaitEvent(st, after, 0));
     CHK(ev.begin(3, st)); hptk_resolve(st, ctx->max_blocks, ps, accum, minmax); CHK(ev.end(st));
@@ -905,8 +931,17 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
         ps.pixel_list = pixel_list; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
         ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
         ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
-        CHK(run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s, inflight), set ? ctx->aux_stream[set - 1] : st,
-                     inflight > 1 && passes > 0 ? ctx->ev_done[(set + inflight - 1) % inflight] : nullptr, inflight > 1 ? ctx->ev_done[set] : nullptr));
+        const int rc = run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s, inflight), set ? ctx->aux_stream[set - 1] : st,
+                                inflight > 1 && passes > 0 ? ctx->ev_done[(set + inflight - 1) % inflight] : nullptr, inflight > 1 ? ctx->ev_done[set] : nullptr);
+        if (rc != HPT_OK) {
+            // the aux streams were forked off the context stream and hold passes of this call: drain them before the error
+            // leaves, so that the caller's stream is again the only one with work of this context (g_err keeps rc's text)
+            const std::string keep = g_err;
+            for (int k = 1; k < inflight; ++k) (void)hipStreamSynchronize(ctx->aux_stream[k - 1]);
+            (void)hipStreamSynchronize(st); (void)hipGetLastError();
+            g_err = keep;
+            return rc;
+        }
         ++passes;
         if (per_sample_host) {
             rad.resize((size_t)npix * cur * 4);
@@ -999,12 +1034,7 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
         CHK(s->w_list[0].ensure(npix * sizeof(uint32_t))); CHK(s->w_list[1].ensure(npix * sizeof(uint32_t)));
         CHK(s->w_listcount.ensure(sizeof(uint32_t)));
         // min = +inf, max = 0 (main.rs:90-92)
-        {
-            std::vector<float> init(npix * 6);
-            for (uint64_t i = 0; i < npix; ++i) { for (int c = 0; c < 3; ++c) { init[6 * i + c] = INFINITY; init[6 * i + 3 + c] = 0.0f; } }
-            HIPCHK(hipMemcpyAsync(s->w_minmax.p, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));
-        }
+        hptk_init_minmax(st, ctx->max_blocks, s->w_minmax.as<float>(), (uint32_t)npix);
         hptk_fill_u32(st, ctx->max_blocks, s->w_spp.as<uint32_t>(), npix, (uint32_t)p->initial_samples);
         int have = 0, num_samples = p->initial_samples, cur_list = -1;   // -1: all pixels
         uint32_t n_active = (uint32_t)npix;

@@ -1302,6 +1302,11 @@ __global__ void __launch_bounds__(HPT_BLOCK)
 k_fill_f32(float* p, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * HPT_BLOCK) p[i] = v;
 }
+// main.rs:90-92: per pixel min = +inf (r, g, b), max = 0 (r, g, b)
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_init_minmax(float* p, uint32_t npix) {
+    for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < (size_t)npix * 6; i += (size_t)gridDim.x * HPT_BLOCK) p[i] = (i % 6) < 3 ? HPT_INF : 0.0f;
+}
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_fill_u32(uint32_t* p, size_t n, uint32_t v) {
     for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * HPT_BLOCK) p[i] = v;
@@ -1396,36 +1401,31 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
 }
-size_t hptk_extend_lds_bytes(int stack_entries, const DScene& sc) {
-    stack_entries = carve_entries(stack_entries, sc.use_tlas != 0);
-    return trav_lds_bytes(stack_entries, scene_lds_mode(stack_entries, sc));
-}
-// workgroups of k_extend one CU keeps resident (registers and LDS of the variant that will be launched): the grid of a
-// persistent kernel with statically strided work must not exceed it, or the surplus workgroups start when the others end
-int hptk_extend_blocks_per_cu(int stack_entries, const DScene& sc) {
-    const int se = carve_entries(stack_entries, sc.use_tlas != 0);
-    return extend_resident(sc, scene_lds_mode(se, sc) == LDS_TLAS, hptk_extend_lds_bytes(stack_entries, sc));
+// Everything about a scene's launches that depends only on the committed scene (LDS layout, kernel variant, resident
+// workgroups per CU): computed once by hpt_scene_commit -- the occupancy queries cost host time that would otherwise sit
+// between the 576 launches of a frame.  Must run with the scene's device current.
+void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPlan* out) {
+    HptkPlan p;
+    p.extend_entries = carve_entries(stack_entries, sc.use_tlas != 0);
+    p.extend_mode = scene_lds_mode(p.extend_entries, sc);
+    p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode);
+    p.extend_per_cu = extend_resident(sc, p.extend_mode == LDS_TLAS, p.extend_lds);
+    p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
+    p.shade_lds = p.shade_tables <= 24 * 1024;
+    // resident workgroups of k_shade per CU (0: query failed); the pass launches a multiple of it -- work is strided
+    // statically over the grid, so a grid of 1.6 x the resident workgroups runs one full round and one at 60 %
+    p.shade_per_cu = p.shade_lds ? resident_blocks(k_shade<true>, p.shade_tables) : resident_blocks(k_shade<false>, 0);
+    *out = p;
 }
 static int g_refill = 24;
 void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
-void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count) {
-    stack_entries = carve_entries(stack_entries, sc.use_tlas != 0);
-    const int mode = scene_lds_mode(stack_entries, sc);
-    const size_t lds = trav_lds_bytes(stack_entries, mode);
+void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, bool count) {
     // one kernel per (instrumented, two-level, node format, deferral) combination: each path gets its own register allocation
-    auto k = count ? extend_kernel<true>(sc, mode == LDS_TLAS) : extend_kernel<false>(sc, mode == LDS_TLAS);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(HPT_BLOCK), lds, st, sc, ps, depth, stack_entries, g_refill);
+    auto k = count ? extend_kernel<true>(sc, plan.extend_mode == LDS_TLAS) : extend_kernel<false>(sc, plan.extend_mode == LDS_TLAS);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(HPT_BLOCK), plan.extend_lds, st, sc, ps, depth, plan.extend_entries, g_refill);
 }
-// resident workgroups of k_shade per CU (0: query failed); the pass launches a multiple of it -- work is strided
-// statically over the grid, so a grid of 1.6 x the resident workgroups runs one full round and one at 60 %
-static bool shade_tables_in_lds(size_t tables) { return tables <= 24 * 1024; }
-int hptk_shade_blocks_per_cu(const DScene& sc, int n_xf, int n_mat) {
-    const size_t tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
-    return shade_tables_in_lds(tables) ? resident_blocks(k_shade<true>, tables) : resident_blocks(k_shade<false>, 0);
-}
-void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {
-    const size_t tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
-    if (shade_tables_in_lds(tables)) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(HPT_BLOCK), tables, st, sc, ps, depth, n_xf, n_mat);
+void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {
+    if (plan.shade_lds) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(HPT_BLOCK), plan.shade_tables, st, sc, ps, depth, n_xf, n_mat);
     else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth, n_xf, n_mat);
 }
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax) {
@@ -1439,6 +1439,9 @@ void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_lis
 }
 void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v) {
     hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, p, n, v);
+}
+void hptk_init_minmax(hipStream_t st, int max_blocks, float* p, uint32_t npix) {
+    hipLaunchKernelGGL(k_init_minmax, dim3(grid_for((uint64_t)npix * 6, max_blocks)), dim3(HPT_BLOCK), 0, st, p, npix);
 }
 void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32_t v) {
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, p, n, v);

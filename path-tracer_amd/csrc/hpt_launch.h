@@ -9,16 +9,20 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
                           float4* pos, float4* normal, float4* uvw);
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps);
-void hptk_extend(hipStream_t st, int blocks, int stack_entries, const DScene& sc, const DPass& ps, int depth, bool count);
-void hptk_shade(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat);
+struct HptkPlan {          // what hptk_plan derives from a committed scene (see hpt_kernels.hip)
+    int extend_entries = 1, extend_mode = 0, extend_per_cu = 0;   // stack entries carved, LDS layout, resident workgroups per CU (0: query failed)
+    size_t extend_lds = 0;
+    size_t shade_tables = 0; bool shade_lds = false; int shade_per_cu = 0;
+};
+void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPlan* out);
+void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, bool count);
+void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat);
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax);
 void hptk_finish_pass(hipStream_t st, const DPass& ps);
 void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_list, uint32_t n_in, const float* minmax, const float thr[3],
                           uint32_t* out_list, uint32_t* out_count, uint32_t* samples_per_px, uint32_t num_samples_next);
 void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v);
+void hptk_init_minmax(hipStream_t st, int max_blocks, float* p, uint32_t npix);      // main.rs:90-92
 void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32_t v);
 void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n);
 void hptk_set_refill(int lanes);   // tuning: idle lanes per wave that trigger a refill in drain_queue
-size_t hptk_extend_lds_bytes(int stack_entries, const DScene& sc);   // dynamic LDS one k_extend workgroup asks for
-int hptk_extend_blocks_per_cu(int stack_entries, const DScene& sc);
-int hptk_shade_blocks_per_cu(const DScene& sc, int n_xf, int n_mat);   // resident workgroups of k_shade per CU (0: query failed)   // resident workgroups per CU (0: query failed)
