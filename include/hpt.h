@@ -201,6 +201,21 @@ int hpt_render(hpt_scene* scene, const hpt_render_params* params, float* rgb, ui
  * context stream before returning only if stats != NULL. */
 int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
                       hpt_render_stats* stats);
+/* hpt_render_device for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference (its main.rs:55 allocates the frame buffer per run).  Same
+ * arguments, same kernels and bit-identical output as hpt_render_device, but the pass buffers (wavefront queues, hit and
+ * radiance records, counters, Halton table) come from a static device array of HPT_NOALLOC_SCRATCH_MB (72) MB that each
+ * GPU the library runs on holds until the process ends, instead of from hipMalloc: the call allocates nothing (no
+ * hipMalloc / hipFree, no stream or event creation).  Limits (HPT_ERR_LIMIT beyond them): the frame has at most
+ * HPT_NOALLOC_MAX_PIXELS = 2^19 pixels (the reference's 800 x 600 fits) and a call renders at most HPT_NOALLOC_MAX_SPP =
+ * 4096 samples (continue with first_sample).  Fixed-spp only; HPT_RENDER_TIME_KERNELS is refused (it creates events).
+ * One pass at a time on the context stream.  Every call on a GPU shares that GPU's one array (whatever the context or
+ * scene): calls that overlap on one GPU race -- serialise them. */
+#define HPT_NOALLOC_MAX_PIXELS (1u << 19)
+#define HPT_NOALLOC_MAX_SPP 4096
+#define HPT_NOALLOC_SCRATCH_MB 72
+int hpt_render_device_noalloc(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
+                              hpt_render_stats* stats);
 /* One round of the adaptive loop (main.rs:72-99 restricted to a sample range) on DEVICE buffers, for hosts that
  * drive the rounds themselves -- a rank of a multi-GPU adaptive render renders its share of the round's samples and
  * all-reduces the min/max planes before the contrast test.  params: adaptive = 0, first_sample, spp =

@@ -74,6 +74,7 @@ struct hpt_context {
     std::vector<hipEvent_t> events;   // pool for HPT_RENDER_TIME_KERNELS and the trace entry's kernel timing
     int live_scenes = 0;              // scenes created on this context and not yet destroyed
     bool destroy_pending = false;     // hpt_context_destroy was called while scenes were live: freed with the last scene
+    void* scratch = nullptr; size_t scratch_bytes = 0;   // this device's copy of the static no-alloc workspace (hptk_scratch)
 };
 
 struct HostMesh {
@@ -205,6 +206,8 @@ static int context_init(hpt_context* c) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (hipEvent_t& e : c->ev_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->stream = c->own_stream;
+    // this device's address of the static workspace of the no-alloc entry point (once per device, with it current)
+    CHK(hptk_scratch(device, &c->scratch, &c->scratch_bytes));
     return HPT_OK;
 }
 // Scenes keep a pointer to their context (device, streams): destroying the context first would leave them dangling
@@ -962,11 +965,11 @@ static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, 
     return render_range(s, p, nullptr, (uint32_t)((uint64_t)s->ds.cam.w * s->ds.cam.h), accum, nullptr, per_sample_host, stats, ev);
 }
 
-static int finish_stats(hpt_scene* s, hpt_render_stats* stats, EventLog& ev, double t0) {
+static int finish_stats(hpt_scene* s, hpt_render_stats* stats, EventLog& ev, double t0, const void* d_stat = nullptr) {
     if (!stats) return HPT_OK;
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     unsigned long long h[8];
-    HIPCHK(hipMemcpy(h, s->w_stat.p, sizeof h, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h, d_stat ? d_stat : s->w_stat.p, sizeof h, hipMemcpyDeviceToHost));
     stats->rays_primary = h[4]; stats->rays_bounce = h[0] - h[4];
     stats->nodes_visited = h[1]; stats->tris_tested = h[2]; stats->inst_tests = h[3];
     double k[4];
@@ -991,6 +994,67 @@ extern "C" int hpt_render_device(hpt_scene* s, const hpt_render_params* p, float
     EventLog ev{ctx, stats && (p->flags & HPT_RENDER_TIME_KERNELS)};
     CHK(render_fixed(s, p, rgb_sum_device, nullptr, stats, ev));
     return finish_stats(s, stats, ev, t0);
+}
+
+// hpt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc): the pass buffers -- wavefront queues, hit and radiance records, append counters, statistics, Halton
+// table -- are carved from this device's copy of the static `scratch` array of hpt_kernels.hip (ctx->scratch, resolved
+// once per device by hipGetSymbolAddress in hpt_context_create) instead of the scene's grow-only hipMalloc workspace.
+// One pass at a time on the context stream; calls no hipMalloc / hipFree / event or stream creation, and no host
+// allocation either (the Halton table is built on the stack).  Same kernels, same pass order, same sums as
+// hpt_render_device -> bit-identical output.  Every call on a GPU uses that GPU's one array: overlapping calls race.
+extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* p, float* rgb_sum_device, hpt_render_stats* stats) {
+    CHK(check_params(s, p));
+    if (p->adaptive) return fail(HPT_ERR_INVALID, "hpt_render_device_noalloc: fixed-spp only");
+    if (!rgb_sum_device) return fail(HPT_ERR_INVALID, "hpt_render_device_noalloc: null output");
+    if (p->flags & HPT_RENDER_TIME_KERNELS) return fail(HPT_ERR_INVALID, "hpt_render_device_noalloc: HPT_RENDER_TIME_KERNELS creates HIP events; not available here");
+    hpt_context* ctx = s->ctx;
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    if (npix > HPT_NOALLOC_MAX_PATHS)
+        return fail(HPT_ERR_LIMIT, "hpt_render_device_noalloc: frame of %llu pixels exceeds the static workspace (at most %u pixels, e.g. 800 x 600); use hpt_render_device",
+                    (unsigned long long)npix, (unsigned)HPT_NOALLOC_MAX_PATHS);
+    if (p->spp > HPT_NOALLOC_MAX_SPP)
+        return fail(HPT_ERR_LIMIT, "hpt_render_device_noalloc: %d samples per call exceed the static workspace (at most %d; split the range with first_sample)", p->spp, HPT_NOALLOC_MAX_SPP);
+    if (!ctx->scratch || ctx->scratch_bytes < (size_t)HPT_NOALLOC_SCRATCH_BYTES) return fail(HPT_ERR_STATE, "hpt_render_device_noalloc: the static workspace of this device was not resolved");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const double t0 = now_s();
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    unsigned char* base = (unsigned char*)ctx->scratch;
+    DPass ps; std::memset(&ps, 0, sizeof ps);
+    for (int a = 0; a < 2; ++a) {
+        ps.q[a].ray_o = (float4*)(base + HPT_NOALLOC_OFF_Q(3 * a + 0));
+        ps.q[a].ray_d = (float4*)(base + HPT_NOALLOC_OFF_Q(3 * a + 1));
+        ps.q[a].thr = (float4*)(base + HPT_NOALLOC_OFF_Q(3 * a + 2));
+    }
+    ps.hit = (float4*)(base + HPT_NOALLOC_OFF_HIT); ps.radiance = (float4*)(base + HPT_NOALLOC_OFF_RADIANCE);
+    ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
+    ps.stat = (unsigned long long*)(base + HPT_NOALLOC_OFF_STAT);
+    float2* d_halton = (float2*)(base + HPT_NOALLOC_OFF_HALTON);
+    // the array keeps the last call's contents: statistics start at zero here, counters and radiance per pass (run_pass)
+    HIPCHK(hipMemsetAsync(ps.stat, 0, 8 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(rgb_sum_device, 0, npix * 3 * sizeof(float), st));
+    float hal[2 * 64];      // Halton values of one pass's samples, staged on the stack
+    // as many samples of every pixel per pass as the workspace holds (hpt_render_device: 64 M paths per pass)
+    int S = (int)std::min<uint64_t>(std::min<uint64_t>(HPT_NOALLOC_MAX_PATHS / npix, 64), (uint64_t)p->spp);
+    if (p->spp_per_pass > 0) S = std::min(S, p->spp_per_pass);
+    EventLog ev{ctx, false};
+    uint32_t passes = 0;
+    for (int done = 0; done < p->spp; done += S) {
+        const int cur = std::min(S, p->spp - done);
+        for (int k = 0; k < cur; ++k) { hal[2 * k] = hpt_halton(p->first_sample + done + k + 1, 2); hal[2 * k + 1] = hpt_halton(p->first_sample + done + k + 1, 3); }
+        HIPCHK(hipMemcpyAsync(d_halton + done, hal, (size_t)cur * sizeof(float2), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));      // `hal` is reused by the next pass (pageable host memory)
+        ps.halton = d_halton + done;
+        ps.pixel_list = nullptr; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
+        ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
+        ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
+        if ((uint64_t)ps.shard_cap * HPT_SHARDS > HPT_NOALLOC_SLOTS) return fail(HPT_ERR_LIMIT, "hpt_render_device_noalloc: pass of %llu paths does not fit the static workspace", (unsigned long long)(npix * (uint64_t)cur));
+        CHK(run_pass(s, ps, rgb_sum_device, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s, 1), st, nullptr, nullptr));
+        ++passes;
+    }
+    if (stats) { stats->passes = passes; stats->samples = npix * (uint64_t)p->spp; }
+    return finish_stats(s, stats, ev, t0, ps.stat);
 }
 
 extern "C" int hpt_render_samples(hpt_scene* s, const hpt_render_params* p, float* per_sample) {

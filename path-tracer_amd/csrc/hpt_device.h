@@ -47,6 +47,24 @@
 //      HPT_QUEUE_CAP         // LDS ray rings of k_extend, one per wave (HPT_QUEUE_CAP / 4 items each: < 64 left + 64 appended):
 //                            // rays that entered a mesh box, waiting for traversal
 
+// ---- static workspace of hpt_render_device_noalloc (hpt_kernels.hip `scratch`) ----
+#define HPT_NOALLOC_MAX_PATHS (1u << 19)   // pixels of the largest frame it renders (one sample of every pixel per pass; the reference's 800 x 600 fits)
+#ifndef HPT_NOALLOC_MAX_SPP
+#define HPT_NOALLOC_MAX_SPP 4096           // samples per call (size of the Halton table); include/hpt.h states the same limits
+#endif
+// queue slots: 64 segments, each rounded up to whole 256-path chunks
+#define HPT_NOALLOC_SLOTS ((size_t)HPT_NOALLOC_MAX_PATHS + (size_t)HPT_SHARDS * HPT_BLOCK)
+#define HPT_ALIGN256(x) (((size_t)(x) + 255) & ~(size_t)255)
+// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), counters, statistics, Halton
+#define HPT_NOALLOC_OFF_Q(k) ((size_t)(k) * HPT_ALIGN256(HPT_NOALLOC_SLOTS * 16))
+#define HPT_NOALLOC_OFF_HIT HPT_NOALLOC_OFF_Q(6)
+#define HPT_NOALLOC_OFF_RADIANCE HPT_NOALLOC_OFF_Q(7)
+#define HPT_NOALLOC_OFF_HIT_INST HPT_NOALLOC_OFF_Q(8)
+#define HPT_NOALLOC_OFF_COUNTS (HPT_NOALLOC_OFF_HIT_INST + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 4))
+#define HPT_NOALLOC_OFF_STAT (HPT_NOALLOC_OFF_COUNTS + HPT_ALIGN256((size_t)HPT_COUNTS_TOTAL * 4))
+#define HPT_NOALLOC_OFF_HALTON (HPT_NOALLOC_OFF_STAT + 256)
+#define HPT_NOALLOC_SCRATCH_BYTES (HPT_NOALLOC_OFF_HALTON + HPT_ALIGN256((size_t)HPT_NOALLOC_MAX_SPP * 8))
+
 struct DMesh {
     int32_t root_ref;     // ref of the root (interior index or ~tri for a one-triangle mesh)
     int32_t tri_base;     // global index of this mesh's triangle 0

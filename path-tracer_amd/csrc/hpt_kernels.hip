@@ -1449,3 +1449,30 @@ void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32
 void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n) {
     hipLaunchKernelGGL(k_divide, dim3(grid_for(npix, max_blocks)), dim3(HPT_BLOCK), 0, st, accum, samples, out, npix, fixed_n);
 }
+
+// ------------------------------------------------------------------------------------------------ static workspace
+// The pass buffers of hpt_render_device_noalloc (include/hpt.h): wavefront queues, hit records, radiance records, append
+// counters, statistics, Halton table for a frame of up to HPT_NOALLOC_MAX_PATHS pixels -- HPT_NOALLOC_SCRATCH_BYTES
+// (71.9 MB) of device memory that every GPU the library runs on holds from the first load of this code object to the end
+// of the process.  The array's NAME is a host-side stand-in, not a device address: host code gets each device's copy
+// through hipGetSymbolAddress (once per device, with that device current) and uses that pointer -- for kernel arguments,
+// hipMemsetAsync and copies alike.  The kernels take the pointer as an argument, exactly as they take the hipMalloc'ed
+// pass buffers of hpt_render_device.
+static __device__ __align__(256) unsigned char scratch[HPT_NOALLOC_SCRATCH_BYTES];   // (no attribute "used": it keeps the symbol local, and the host-side lookup needs the externalised one)
+#include <mutex>
+int hptk_scratch(int device, void** out, size_t* bytes) {
+    static std::mutex mu;
+    static void* ptr[64] = {};      // per device: each GPU holds its own copy of the array at its own address
+    if (device < 0 || device >= 64) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[device]) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device) return -2;      // the caller makes the device current first
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) { (void)hipGetLastError(); return -2; }
+        ptr[device] = p;
+    }
+    *out = ptr[device]; *bytes = (size_t)HPT_NOALLOC_SCRATCH_BYTES;
+    return 0;
+}

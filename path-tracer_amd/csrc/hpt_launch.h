@@ -23,6 +23,9 @@ void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_lis
                           uint32_t* out_list, uint32_t* out_count, uint32_t* samples_per_px, uint32_t num_samples_next);
 void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v);
 void hptk_init_minmax(hipStream_t st, int max_blocks, float* p, uint32_t npix);      // main.rs:90-92
+// this device's address of the static workspace of the no-alloc entry point (hipGetSymbolAddress, once per device; the
+// device must be current).  0 on success.
+int hptk_scratch(int device, void** out, size_t* bytes);
 void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32_t v);
 void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n);
 void hptk_set_refill(int lanes);   // tuning: idle lanes per wave that trigger a refill in drain_queue

@@ -72,7 +72,7 @@ EXPORTS = [
     "hpt_scene_create", "hpt_scene_destroy", "hpt_scene_add_mesh", "hpt_scene_add_image", "hpt_scene_add_material",
     "hpt_scene_add_node", "hpt_scene_set_background", "hpt_scene_set_environment", "hpt_scene_set_camera", "hpt_scene_commit",
     "hpt_trace_rays", "hpt_trace_rays_device", "hpt_scene_intersect", "hpt_render", "hpt_render_device", "hpt_render_samples",
-    "hpt_scene_info", "hpt_render_round_device", "hpt_adaptive_select_device",
+    "hpt_scene_info", "hpt_render_round_device", "hpt_adaptive_select_device", "hpt_render_device_noalloc",
 ]
 
 
@@ -137,6 +137,7 @@ def _load():
     lib.hpt_scene_intersect.argtypes = [C.c_void_p, C.c_int64, F32P, F32P, I32P, I32P, F32P, U8P, F32P, F32P, F32P]
     lib.hpt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), F32P, U32P, C.POINTER(RenderStats)]
     lib.hpt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
+    lib.hpt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
     lib.hpt_render_samples.argtypes = [C.c_void_p, C.POINTER(RenderParams), F32P]
     lib.hpt_scene_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
     lib.hpt_render_round_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
@@ -329,6 +330,13 @@ class Scene:
         p = self.params(**kw)
         st = RenderStats()
         check(lib.hpt_render_device(self.h, C.byref(p), C.c_void_p(out_ptr), C.byref(st) if want_stats else None))
+        return st
+
+    def render_device_noalloc(self, out_ptr, want_stats=False, **kw):
+        """hpt_render_device_noalloc: pass buffers from the library's static device array, nothing allocated"""
+        p = self.params(**kw)
+        st = RenderStats()
+        check(lib.hpt_render_device_noalloc(self.h, C.byref(p), C.c_void_p(out_ptr), C.byref(st) if want_stats else None))
         return st
 
     def info(self):
