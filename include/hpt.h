@@ -11,8 +11,10 @@
  *    of the last error on the calling thread is hpt_last_error().  (The reference panics, exit 101, on every error.)
  *  - plain pointers and sizes only.  The library copies every input array during the call (caller keeps ownership).
  *  - matrices are 3x3 COLUMN-major float[9] (m[c*3+r]) like cgmath::Matrix3 (scene.rs:102-105 Transform).
- *  - one hpt_context drives ONE GPU from one host thread (one process per GPU); multi-GPU = one context per rank,
- *    each rendering a sample range (first_sample, spp) of every pixel, summed afterwards (RCCL; see bench.py).
+ *  - one hpt_context drives ONE GPU from one host thread.  Several GPUs: either one process per GPU, each with its own
+ *    context rendering a sample range (first_sample, spp) of every pixel, summed afterwards (bench.py: torch.distributed
+ *    over RCCL), or ONE process and an hpt_group (below), which does the split and the RCCL reduce itself.
+ *  - destroy scenes before their context (a context destroyed earlier is kept alive until its last scene goes).
  *  - a context is not thread-safe.  All work of a context is ordered on one HIP stream (its own, or the one
  *    given to hpt_context_set_stream): it starts behind what that stream holds and is complete when that stream
  *    reaches the end of the call's work (a render runs every other pass on a second stream of the library's own,
@@ -233,6 +235,33 @@ int hpt_adaptive_select_device(hpt_scene* scene, const uint32_t* list_in_device,
 /* optional per-sample radiance dump for parity tests (fixed mode): per_sample = W*H*spp*3 floats on the HOST,
  * pixel-major then sample. */
 int hpt_render_samples(hpt_scene* scene, const hpt_render_params* params, float* per_sample);
+
+/* ---- one call that uses every GPU of the node: main.rs:57-115 (one loop nest that saturates the whole machine) ----
+ * A group holds one context per listed GPU (n_devices == 0: every GPU the process sees) and, unless a device is listed
+ * twice or HPT_GROUP_TRANSPORT=p2p is set, an RCCL communicator over them (ncclCommInitAll; librccl.so.1 is loaded at
+ * this call).  The host builds and commits ONE scene on hpt_group_context(group, 0); hpt_group_render replicates it on
+ * the other GPUs (again whenever it was re-committed), renders a contiguous share of the samples of every pixel on each
+ * GPU from a host thread of its own, sum-reduces the float accumulators onto GPU 0 (ncclReduce over xGMI; transport p2p:
+ * peer copies + adds in rank order) and returns sum / num_samples on the host like hpt_render.  The RNG is keyed by
+ * (pixel, sample), so the set of paths does not depend on the number of GPUs; only the grouping of the float sums does.
+ * Adaptive mode runs the rounds of main.rs:67-107 in lock step: min/max planes all-reduced per round, identical active
+ * sets on every GPU, per-pixel sample counts identical to the one-GPU render.
+ * Destroy the scene before the group.  Not thread-safe; one host thread drives a group. */
+typedef struct hpt_group hpt_group;
+typedef struct {
+    int32_t n_devices;
+    int32_t transport;                 /* 0: RCCL collectives, 1: peer copies + ordered adds */
+    uint64_t rays_primary, rays_bounce, samples;   /* over all GPUs */
+    double seconds_render_max;         /* the slowest GPU's render time (host clock around its calls) */
+    double seconds_reduce;             /* the exchange steps: accumulator reduce (+ min/max all-reduces in adaptive mode) */
+    double seconds_total;
+} hpt_group_stats;
+int hpt_group_create(const int* devices, int n_devices, hpt_group** out);
+void hpt_group_destroy(hpt_group* group);
+int hpt_group_size(const hpt_group* group);
+hpt_context* hpt_group_context(hpt_group* group, int rank);
+int hpt_group_render(hpt_group* group, hpt_scene* scene, const hpt_render_params* params, float* rgb, uint32_t* samples_per_px,
+                     hpt_group_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@
 #include "../../include/hpt.h"
 #include "hpt_bvh.h"
 #include "hpt_device.h"
+#include "hpt_internal.h"
 #include "hpt_launch.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -97,6 +98,7 @@ struct hpt_scene {
     hpt_texture background, environment;
     hpt_camera camera;
     bool have_camera = false, committed = false;
+    uint64_t generation = 0;    // commits so far (a group re-replicates a scene that was committed again)
     // device side
     DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_meshinst, d_xinv, d_xfwd, d_materials, d_images, d_pool;
     std::vector<DMesh> h_meshes;
@@ -650,7 +652,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     // k_shade: two rounds of exactly the resident workgroups (5/CU -> 10/CU measured best: 8/CU +3 %, 4/CU +8 %)
     s->shade_grid = s->plan.shade_per_cu > 0 ? ctx->num_cus * s->plan.shade_per_cu * 2 : ctx->max_blocks;
     if (const char* e = getenv("HPT_SHADE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) s->shade_grid = ctx->num_cus * v; }
-    s->committed = true;
+    s->committed = true; s->generation++;
     return HPT_OK;
 }
 
@@ -1184,6 +1186,32 @@ extern "C" int hpt_scene_info(hpt_scene* s, hpt_scene_info_t* out) {
     out->n_nodes = s->ds.n_nodes; out->n_triangles = s->n_tris_total; out->tlas_nodes = s->tlas_nodes;
     out->uses_tlas = s->ds.use_tlas; out->stack_entries = s->stack_entries; out->device_bytes = s->device_bytes;
     out->node_bytes = s->node_bytes; out->trees_optimized = s->trees_optimized;
+    return HPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ internal seams (hpt_internal.h)
+int hpti_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+uint64_t hpti_scene_generation(const hpt_scene* s) { return s->generation; }
+hpt_context* hpti_scene_context(const hpt_scene* s) { return s->ctx; }
+void hpti_scene_frame(const hpt_scene* s, uint32_t* w, uint32_t* h) { *w = s->camera.img_width; *h = s->camera.img_height; }
+hipStream_t hpti_context_stream(const hpt_context* c) { return c->stream; }
+int hpti_context_device(const hpt_context* c) { return c->device; }
+int hpti_context_max_blocks(const hpt_context* c) { return c->max_blocks; }
+int hpti_scene_clone(const hpt_scene* src, hpt_context* ctx, hpt_scene** out) {
+    if (!src || !ctx || !out) return fail(HPT_ERR_INVALID, "scene clone: null argument");
+    if (!src->committed) return fail(HPT_ERR_STATE, "scene not committed: call hpt_scene_commit first");
+    hpt_scene* s = nullptr;
+    CHK(hpt_scene_create(ctx, &s));
+    s->meshes = src->meshes; s->nodes = src->nodes; s->top = src->top; s->materials = src->materials; s->images = src->images;
+    s->background = src->background; s->environment = src->environment; s->camera = src->camera; s->have_camera = src->have_camera;
+    const int rc = hpt_scene_commit(s);
+    if (rc != HPT_OK) { const std::string keep = g_err; hpt_scene_destroy(s); g_err = keep; return rc; }
+    *out = s;
     return HPT_OK;
 }
 

@@ -1322,6 +1322,25 @@ k_divide(const float* __restrict__ accum, const uint32_t* __restrict__ samples, 
     }
 }
 
+// ---- combining the per-GPU partial results of a group render (hpt_group.cpp) ----
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_add_f32(float* __restrict__ dst, const float* __restrict__ src, size_t n) {      // sum of the float accumulators, rank order
+    for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * HPT_BLOCK) dst[i] += src[i];
+}
+// running per-channel min / max planes (npix x 6: min rgb, max rgb; main.rs:90-100) of two ranks folded together
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_minmax_merge(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * HPT_BLOCK) {
+        const float a = dst[i], b = src[i];
+        dst[i] = (i % 6) < 3 ? (b < a ? b : a) : (b > a ? b : a);
+    }
+}
+// sign flip of the min half of the planes: max over [-min, max] combines both with ONE all-reduce (exact)
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_negate_min(float* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * HPT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * HPT_BLOCK) if ((i % 6) < 3) p[i] = -p[i];
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static inline int grid_for(uint64_t n, int max_blocks) {
     uint64_t b = (n + HPT_BLOCK - 1) / HPT_BLOCK;
@@ -1439,6 +1458,15 @@ void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_lis
 }
 void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v) {
     hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, p, n, v);
+}
+void hptk_add_f32(hipStream_t st, int max_blocks, float* dst, const float* src, size_t n) {
+    hipLaunchKernelGGL(k_add_f32, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, dst, src, n);
+}
+void hptk_minmax_merge(hipStream_t st, int max_blocks, float* dst, const float* src, size_t n) {
+    hipLaunchKernelGGL(k_minmax_merge, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, dst, src, n);
+}
+void hptk_negate_min(hipStream_t st, int max_blocks, float* p, size_t n) {
+    hipLaunchKernelGGL(k_negate_min, dim3(grid_for(n, max_blocks)), dim3(HPT_BLOCK), 0, st, p, n);
 }
 void hptk_init_minmax(hipStream_t st, int max_blocks, float* p, uint32_t npix) {
     hipLaunchKernelGGL(k_init_minmax, dim3(grid_for((uint64_t)npix * 6, max_blocks)), dim3(HPT_BLOCK), 0, st, p, npix);

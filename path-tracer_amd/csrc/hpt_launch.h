@@ -22,6 +22,10 @@ void hptk_finish_pass(hipStream_t st, const DPass& ps);
 void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_list, uint32_t n_in, const float* minmax, const float thr[3],
                           uint32_t* out_list, uint32_t* out_count, uint32_t* samples_per_px, uint32_t num_samples_next);
 void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v);
+// group render (hpt_group.cpp): partial results of the ranks combined on one device
+void hptk_add_f32(hipStream_t st, int max_blocks, float* dst, const float* src, size_t n);
+void hptk_minmax_merge(hipStream_t st, int max_blocks, float* dst, const float* src, size_t n);
+void hptk_negate_min(hipStream_t st, int max_blocks, float* p, size_t n);
 void hptk_init_minmax(hipStream_t st, int max_blocks, float* p, uint32_t npix);      // main.rs:90-92
 // this device's address of the static workspace of the no-alloc entry point (hipGetSymbolAddress, once per device; the
 // device must be current).  0 on success.

@@ -21,6 +21,8 @@ static void usage() {
         "  --seed S           seed of the counter-based generator (default 1)\n"
         "  --size WxH         override <width>/<height> of the scene file\n"
         "  --device I         GPU index (default 0)\n"
+        "  --gpus N           one call over the first N GPUs (0 = all): hpt_group_render -- samples split over the GPUs, RCCL\n"
+        "                     sum-reduce onto GPU 0 (also: HPT_GPUS=N in the environment, as rust/main_render.rs reads it)\n"
         "  --library-bvh      let the library build its SAH tree instead of handing over the bvh.rs tree\n"
         "  --stats            print ray counts and timings to stderr\n"
         "  --dump-scene FILE  write the loaded scene (exact float bits + digests) and exit; needs no GPU\n");
@@ -31,6 +33,8 @@ int main(int argc, char** argv) {
         std::vector<std::string> pos;
         int spp = 0, depth = 8, device = 0; unsigned seed = 1; bool library_bvh = false, stats = false;
         int ow = 0, oh = 0; std::string dump;
+        int gpus = -1;      // -1: one context on --device; >= 0: a group
+        if (const char* e = std::getenv("HPT_GPUS")) gpus = std::atoi(e);
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
             auto val = [&]() -> const char* { if (i + 1 >= argc) throw Error("missing value after " + a); return argv[++i]; };
@@ -38,6 +42,7 @@ int main(int argc, char** argv) {
             else if (a == "--depth") depth = std::atoi(val());
             else if (a == "--seed") seed = (unsigned)std::strtoul(val(), nullptr, 10);
             else if (a == "--device") device = std::atoi(val());
+            else if (a == "--gpus") gpus = std::atoi(val());
             else if (a == "--size") { if (std::sscanf(val(), "%dx%d", &ow, &oh) != 2 || ow <= 0 || oh <= 0) throw Error("--size wants WxH"); }
             else if (a == "--library-bvh") library_bvh = true;
             else if (a == "--stats") stats = true;
@@ -57,8 +62,13 @@ int main(int argc, char** argv) {
         SceneDesc d = load_scene(pos[0], !library_bvh);
         if (ow) { d.camera.img_width = (uint32_t)ow; d.camera.img_height = (uint32_t)oh; }
 
-        hpt_context* ctx = nullptr; hpt_scene* scene = nullptr;
-        if (hpt_context_create(device, &ctx) != HPT_OK) throw Error(std::string("hpt_context_create: ") + hpt_last_error());
+        hpt_context* ctx = nullptr; hpt_scene* scene = nullptr; hpt_group* group = nullptr;
+        if (gpus >= 0) {      // main.rs:57,72 use the whole machine: so does one hpt_group_render call
+            std::vector<int> devs;
+            for (int i = 0; i < gpus; ++i) devs.push_back(i);
+            if (hpt_group_create(devs.empty() ? nullptr : devs.data(), (int)devs.size(), &group) != HPT_OK) throw Error(std::string("hpt_group_create: ") + hpt_last_error());
+            ctx = hpt_group_context(group, 0);
+        } else if (hpt_context_create(device, &ctx) != HPT_OK) throw Error(std::string("hpt_context_create: ") + hpt_last_error());
         if (hpt_scene_create(ctx, &scene) != HPT_OK) throw Error(std::string("hpt_scene_create: ") + hpt_last_error());
         hand_over(d, scene, library_bvh);
 
@@ -71,8 +81,14 @@ int main(int argc, char** argv) {
         const size_t npix = (size_t)d.camera.img_width * d.camera.img_height;
         std::vector<float> rgb(npix * 3);
         std::vector<uint32_t> counts(npix);
-        hpt_render_stats st;
-        if (hpt_render(scene, &p, rgb.data(), counts.data(), &st) != HPT_OK) throw Error(std::string("hpt_render: ") + hpt_last_error());
+        hpt_render_stats st; std::memset(&st, 0, sizeof st);
+        if (group) {
+            p.flags = 0;
+            hpt_group_stats gs;
+            if (hpt_group_render(group, scene, &p, rgb.data(), counts.data(), &gs) != HPT_OK) throw Error(std::string("hpt_group_render: ") + hpt_last_error());
+            st.rays_primary = gs.rays_primary; st.rays_bounce = gs.rays_bounce; st.samples = gs.samples; st.seconds_total = gs.seconds_total;
+            if (stats) std::fprintf(stderr, "%d GPU(s), %s: slowest render %.3f s, exchange steps %.4f s\n", gs.n_devices, gs.transport ? "peer copies" : "RCCL", gs.seconds_render_max, gs.seconds_reduce);
+        } else if (hpt_render(scene, &p, rgb.data(), counts.data(), &st) != HPT_OK) throw Error(std::string("hpt_render: ") + hpt_last_error());
         std::vector<uint8_t> rgba(npix * 4);
         if (hpt_tonemap_rgba8(rgb.data(), (uint32_t)npix, rgba.data()) != HPT_OK) throw Error(std::string("hpt_tonemap_rgba8: ") + hpt_last_error());
         write_png_rgba8(pos[1], d.camera.img_width, d.camera.img_height, rgba.data());   // main.rs:117
@@ -82,7 +98,8 @@ int main(int argc, char** argv) {
                          d.camera.img_width, d.camera.img_height, (unsigned long long)st.samples, rays, st.seconds_total, rays / st.seconds_total / 1e6,
                          st.seconds_extend, st.seconds_shade, st.passes);
         }
-        hpt_scene_destroy(scene); hpt_context_destroy(ctx);
+        hpt_scene_destroy(scene);
+        if (group) hpt_group_destroy(group); else hpt_context_destroy(ctx);
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "hpt_render: %s\n", e.what());

@@ -64,6 +64,11 @@ class SceneInfo(C.Structure):
                 ("n_triangles", C.c_int64), ("device_bytes", C.c_uint64), ("node_bytes", C.c_int32), ("trees_optimized", C.c_int32)]
 
 
+class GroupStats(C.Structure):
+    _fields_ = [("n_devices", C.c_int32), ("transport", C.c_int32), ("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64),
+                ("samples", C.c_uint64), ("seconds_render_max", C.c_double), ("seconds_reduce", C.c_double), ("seconds_total", C.c_double)]
+
+
 # every symbol include/hpt.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hpt_version", "hpt_last_error", "hpt_device_count", "hpt_rng_f32", "hpt_halton", "hpt_tonemap_rgba8",
@@ -73,6 +78,7 @@ EXPORTS = [
     "hpt_scene_add_node", "hpt_scene_set_background", "hpt_scene_set_environment", "hpt_scene_set_camera", "hpt_scene_commit",
     "hpt_trace_rays", "hpt_trace_rays_device", "hpt_scene_intersect", "hpt_render", "hpt_render_device", "hpt_render_samples",
     "hpt_scene_info", "hpt_render_round_device", "hpt_adaptive_select_device", "hpt_render_device_noalloc",
+    "hpt_group_create", "hpt_group_destroy", "hpt_group_size", "hpt_group_context", "hpt_group_render",
 ]
 
 
@@ -138,6 +144,13 @@ def _load():
     lib.hpt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), F32P, U32P, C.POINTER(RenderStats)]
     lib.hpt_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
     lib.hpt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
+    lib.hpt_group_create.argtypes = [I32P, C.c_int, C.POINTER(C.c_void_p)]
+    lib.hpt_group_destroy.argtypes = [C.c_void_p]
+    lib.hpt_group_destroy.restype = None
+    lib.hpt_group_size.argtypes = [C.c_void_p]
+    lib.hpt_group_context.argtypes = [C.c_void_p, C.c_int]
+    lib.hpt_group_context.restype = C.c_void_p
+    lib.hpt_group_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderParams), F32P, U32P, C.POINTER(GroupStats)]
     lib.hpt_render_samples.argtypes = [C.c_void_p, C.POINTER(RenderParams), F32P]
     lib.hpt_scene_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
     lib.hpt_render_round_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
@@ -195,10 +208,13 @@ def set_tree_opt(mode):
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
+        if _borrowed is not None:      # a context owned by a Group (hpt_group_context): never destroyed from here
+            self.h, self.borrowed = C.c_void_p(_borrowed), True
+            return
         h = C.c_void_p()
         check(lib.hpt_context_create(device, C.byref(h)))
-        self.h = h
+        self.h, self.borrowed = h, False
 
     def set_stream(self, stream_ptr):
         check(lib.hpt_context_set_stream(self.h, C.c_void_p(stream_ptr)))
@@ -210,8 +226,45 @@ class Context:
         check(lib.hpt_context_synchronize(self.h))
 
     def close(self):
-        if getattr(self, "h", None) and lib is not None:
+        if getattr(self, "h", None) and lib is not None and not self.borrowed:
             lib.hpt_context_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Group:
+    """hpt_group_*: one process, several GPUs.  Build ONE scene on `group.context(0)`; `render` replicates it, splits the
+    samples of every pixel over the GPUs and sum-reduces the accumulators onto GPU 0 (RCCL, or peer copies + ordered adds
+    when a device is listed twice / HPT_GROUP_TRANSPORT=p2p)."""
+
+    def __init__(self, devices=None):
+        devs = np.ascontiguousarray(devices if devices is not None else [], dtype=np.int32)
+        h = C.c_void_p()
+        check(lib.hpt_group_create(_p(devs, I32P) if len(devs) else None, len(devs), C.byref(h)))
+        self.h = h
+
+    def size(self):
+        return lib.hpt_group_size(self.h)
+
+    def context(self, rank=0):
+        p = lib.hpt_group_context(self.h, rank)
+        if not p:
+            raise HptError(lib.hpt_last_error().decode())
+        return Context(_borrowed=p)
+
+    def render(self, scene, **kw):
+        p = Scene.params(**kw)
+        rgb = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+        cnt = np.zeros((scene.height, scene.width), dtype=np.uint32)
+        st = GroupStats()
+        check(lib.hpt_group_render(self.h, scene.h, C.byref(p), _p(rgb, F32P), _p(cnt, U32P), C.byref(st)))
+        return dict(rgb=rgb, samples=cnt, stats=st)
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.hpt_group_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -17,7 +17,12 @@ def reduce_sum(tensor, dst=0):
     """Sum the per-rank accumulators onto rank `dst` (in place). No-op without an initialised process group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if tensor.is_cuda and dist.get_backend() == "gloo":      # rehearsal on one GPU: gloo reduces host tensors only
+            host = tensor.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            tensor.copy_(host)
+        else:
+            dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
     return tensor
 
 
@@ -29,7 +34,12 @@ def allreduce_minmax(minmax):
         return minmax
     v = minmax.view(-1, 6)
     v[:, :3].neg_()
-    dist.all_reduce(minmax, op=dist.ReduceOp.MAX)
+    if minmax.is_cuda and dist.get_backend() == "gloo":          # rehearsal on one GPU (see reduce_sum)
+        host = minmax.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX)
+        minmax.copy_(host)
+    else:
+        dist.all_reduce(minmax, op=dist.ReduceOp.MAX)
     v[:, :3].neg_()
     return minmax
 

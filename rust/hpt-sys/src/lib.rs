@@ -5,6 +5,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 pub enum hpt_context {}
 pub enum hpt_scene {}
+pub enum hpt_group {}
 
 pub const HPT_OK: c_int = 0;
 pub const HPT_ERR_INVALID: c_int = -1;
@@ -60,6 +61,13 @@ pub struct hpt_render_stats {
     pub seconds_raygen: f64, pub seconds_extend: f64, pub seconds_shade: f64, pub seconds_resolve: f64,
     pub launches_extend: u32, pub passes: u32,
     pub samples: u64,
+}
+
+#[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+pub struct hpt_group_stats {
+    pub n_devices: i32, pub transport: i32,
+    pub rays_primary: u64, pub rays_bounce: u64, pub samples: u64,
+    pub seconds_render_max: f64, pub seconds_reduce: f64, pub seconds_total: f64,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
@@ -126,4 +134,13 @@ extern "C" {
                                       thresholds: *const f32, list_out_device: *mut u32, samples_per_px_device: *mut u32,
                                       next_num_samples: u32, n_out: *mut u32) -> c_int;
     pub fn hpt_render_samples(scene: *mut hpt_scene, params: *const hpt_render_params, per_sample: *mut f32) -> c_int;
+
+    /// One process, several GPUs: contexts + RCCL communicator (`n_devices == 0`: every GPU the process sees).
+    pub fn hpt_group_create(devices: *const c_int, n_devices: c_int, out: *mut *mut hpt_group) -> c_int;
+    pub fn hpt_group_destroy(group: *mut hpt_group);
+    pub fn hpt_group_size(group: *const hpt_group) -> c_int;
+    pub fn hpt_group_context(group: *mut hpt_group, rank: c_int) -> *mut hpt_context;
+    /// `hpt_render` over the group: samples split over the GPUs, accumulators sum-reduced onto GPU 0 (RCCL).
+    pub fn hpt_group_render(group: *mut hpt_group, scene: *mut hpt_scene, params: *const hpt_render_params, rgb: *mut f32,
+                            samples_per_px: *mut u32, stats: *mut hpt_group_stats) -> c_int;
 }

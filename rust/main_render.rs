@@ -1,5 +1,6 @@
 // Drop-in replacement for main.rs:55-115 of glowcoil/path-tracer (the image buffer + rayon pixel loop around
-// scene.sample): hand the loaded Scene / Camera to libhpt.so and make ONE hpt_render call.  SOURCE ONLY -- no Rust
+// scene.sample): hand the loaded Scene / Camera to libhpt.so and make ONE hpt_group_render call -- every GPU of the node
+// (HPT_GPUS=n limits it to the first n), like the rayon loops used every core.  SOURCE ONLY -- no Rust
 // toolchain in the build image; path-tracer_amd/host/main.cpp is the same sequence in C++, compiled and tested.
 //
 // Needs in the reference: `extern crate hpt_sys;` + `hpt-sys = { path = "../rust/hpt-sys" }` in Cargo.toml, and `pub`
@@ -73,8 +74,14 @@ unsafe fn add_node(hs: *mut hpt_scene, node: &Node, parent: i32, ids: &HashMap<S
 /// main.rs:55-115 -> img: Vec<u8> (RGBA8), ready for save_img (main.rs:117)
 pub fn render_on_gpu(scene: &Scene, camera: &Camera) -> Vec<u8> {
     unsafe {
-        let (mut ctx, mut hs) = (ptr::null_mut(), ptr::null_mut());
-        chk(hpt_context_create(0, &mut ctx));
+        // one context per GPU + the RCCL communicator; the scene is built once, on GPU 0's context, and replicated by the library
+        let gpus: Vec<i32> = match std::env::var("HPT_GPUS").ok().and_then(|v| v.parse::<i32>().ok()) {
+            Some(n) if n > 0 => (0..n).collect(),
+            _ => Vec::new(),                                    // empty list = every GPU the process sees
+        };
+        let (mut group, mut hs) = (ptr::null_mut(), ptr::null_mut());
+        chk(hpt_group_create(if gpus.is_empty() { ptr::null() } else { gpus.as_ptr() }, gpus.len() as i32, &mut group));
+        let ctx = hpt_group_context(group, 0);
         chk(hpt_scene_create(ctx, &mut hs));
         let mut ids = HashMap::new();
         for (name, m) in &scene.materials {   // HashMap<String, Material> -> integer ids (scene.rs:132 lookup per hit disappears)
@@ -97,11 +104,11 @@ pub fn render_on_gpu(scene: &Scene, camera: &Camera) -> Vec<u8> {
                                          max_depth: 8, seed: 1, spp_per_pass: 0, flags: 0 };
         let npix = (camera.img_width * camera.img_height) as usize;
         let mut rgb = vec![0f32; npix * 3];
-        chk(hpt_render(hs, &params, rgb.as_mut_ptr(), ptr::null_mut(), ptr::null_mut()));
+        chk(hpt_group_render(group, hs, &params, rgb.as_mut_ptr(), ptr::null_mut(), ptr::null_mut()));
         let mut img = vec![0u8; npix * 4];
         chk(hpt_tonemap_rgba8(rgb.as_ptr(), npix as u32, img.as_mut_ptr()));   // = color_as_u8_array (scene.rs:362)
         hpt_scene_destroy(hs);
-        hpt_context_destroy(ctx);
+        hpt_group_destroy(group);
         img
     }
 }

@@ -9,6 +9,7 @@ ctx = hpt.Context(0)
 t0 = time.perf_counter(); sc = hpt.Scene(ctx, d); t1 = time.perf_counter() - t0
 info = sc.info()
 out = torch.zeros(1920 * 1080 * 3, device="cuda")
+torch.cuda.synchronize()      # torch fills on its own stream; the library works on the context stream
 sc.render_device(out.data_ptr(), want_stats=True, spp=2, max_depth=8, seed=1)
 st = sc.render_device(out.data_ptr(), want_stats=True, spp=8, max_depth=8, seed=1, flags=hpt.RENDER_TIME_KERNELS)
 rays = st.rays_primary + st.rays_bounce

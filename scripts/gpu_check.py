@@ -65,6 +65,7 @@ def main():
     sb = hpt.Scene(ctx, big, host_bvh=lambda m: host_bvh.build_reference_bvh(m.verts, m.tris))
     import torch
     out = torch.zeros(1920 * 1080 * 3, device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()      # torch fills on its own stream; the library works on the context stream
     for spp_pp in (1, 4, 8):
         sb.render_device(out.data_ptr(), want_stats=True, spp=8, max_depth=8, seed=1, spp_per_pass=spp_pp)
         st = sb.render_device(out.data_ptr(), want_stats=True, spp=16, max_depth=8, seed=1, spp_per_pass=spp_pp, flags=hpt.RENDER_TIME_KERNELS)

@@ -15,6 +15,7 @@ def run(ctx, name, desc, spp, depth, tree=None, S=0):
     t_commit = time.perf_counter() - t0
     npix = desc.camera.width * desc.camera.height
     out = torch.zeros(npix * 3, device="cuda")
+    torch.cuda.synchronize()      # torch fills on its own stream; the library works on the context stream
     sc.render_device(out.data_ptr(), want_stats=True, spp=min(spp, 4), max_depth=depth, seed=1, spp_per_pass=S)
     cst = sc.render_device(out.data_ptr(), want_stats=True, spp=min(spp, 4), max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_COUNTERS)
     st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_TIME_KERNELS)

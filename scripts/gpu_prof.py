@@ -10,6 +10,7 @@ desc.camera.width, desc.camera.height = 1920, 1080
 ctx = hpt.Context(0)
 sc = hpt.Scene(ctx, desc, host_bvh=lambda m: host_bvh.build_reference_bvh(m.verts, m.tris))
 out = torch.zeros(1920 * 1080 * 3, device="cuda")
+torch.cuda.synchronize()      # torch fills on its own stream; the library works on the context stream
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # samples per pass (4 = 8 M paths; 32 = the bench's 66 M)
 st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=8, seed=1, spp_per_pass=S)

@@ -11,6 +11,7 @@ def run(name, desc, tree=True, spp=16, S=4, depth=8, bpc=None):
     if bpc is not None: hpt.lib.hpt_debug_set_extend_blocks(ctx.h, bpc)
     sc = hpt.Scene(ctx, desc, host_bvh=(lambda m: host_bvh.build_reference_bvh(m.verts, m.tris)) if tree else None)
     out = torch.zeros(desc.camera.width * desc.camera.height * 3, device="cuda")
+    torch.cuda.synchronize()      # torch fills on its own stream; the library works on the context stream
     sc.render_device(out.data_ptr(), want_stats=True, spp=4, max_depth=depth, seed=1, spp_per_pass=S)
     cspp = int(os.environ.get("HPT_TIME_COUNTER_SPP", "4"))      # samples of the instrumented run (its pass size changes the tail share)
     cst = sc.render_device(out.data_ptr(), want_stats=True, spp=cspp, max_depth=depth, seed=1, spp_per_pass=max(S, cspp), flags=hpt.RENDER_COUNTERS)

@@ -150,6 +150,7 @@ def test_render_device_matches_host_entry(ctx, desc):
     d = resized(desc, 64, 48)
     gsc = hpt.Scene(ctx, d, host_bvh=host_tree)
     out = torch.zeros(64 * 48 * 3, device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()      # torch filled `out` on ITS stream; the library works on the context's own (nothing orders the two)
     st = gsc.render_device(out.data_ptr(), want_stats=True, spp=8, max_depth=8, seed=1, flags=hpt.RENDER_TIME_KERNELS | hpt.RENDER_COUNTERS)
     img = gsc.render(spp=8, max_depth=8, seed=1)["rgb"]
     np.testing.assert_array_equal((out.cpu().numpy().reshape(48, 64, 3) / np.float32(8)), img)
@@ -174,6 +175,19 @@ def test_adaptive_rounds_api(ctx, olib, desc):
         DeviceRounds(sc, max_depth=4, seed=3)          # default stream: no handle to share
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
+    try:
+        _adaptive_rounds_body(ctx, olib, d, sc, ref, stream)
+    finally:      # whatever happens, the session context goes back to its own stream
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        ctx.set_stream(0)
+        sc.close()
+
+
+def _adaptive_rounds_body(ctx, olib, d, sc, ref, stream):
+    import torch
+    import hpt
+    from hpt.dist import DeviceRounds, render_adaptive
     eng = DeviceRounds(sc, max_depth=4, seed=3)
     rgb, spp = render_adaptive(eng, 0, 1, initial_samples=8, max_samples=32)
     torch.cuda.synchronize()
@@ -206,10 +220,6 @@ def test_adaptive_rounds_api(ctx, olib, desc):
     acc, mm, _ = eng.new_buffers(8)
     with pytest.raises(hpt.HptError):
         sc.render_round_device(acc.data_ptr(), mm.data_ptr(), 0, 0, spp=4, adaptive=True)
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(torch.cuda.default_stream())
-    ctx.set_stream(0)
-    sc.close()
 
 
 def test_progressive_checkpoint_resume(ctx, desc, tmp_path):
@@ -250,6 +260,7 @@ def test_full_size_properties(ctx, desc):
     sc, sc2 = hpt.Scene(ctx, d, host_bvh=host_tree), hpt.Scene(ctx, d2, host_bvh=host_tree)
     npix = 1920 * 1080
     a = torch.zeros(npix * 3, device="cuda"); b = torch.zeros(npix * 3, device="cuda"); c = torch.zeros(npix * 3, device="cuda")
+    torch.cuda.synchronize()      # (torch's fills run on torch's stream, the library on the context's)
     st_a = sc.render_device(a.data_ptr(), want_stats=True, spp=5, max_depth=8, seed=2)
     st_b = sc2.render_device(b.data_ptr(), want_stats=True, spp=5, max_depth=8, seed=2)
     assert st_a.rays_primary == npix * 5 and st_a.rays_bounce <= st_a.rays_primary * 8
@@ -290,6 +301,7 @@ def test_passes_in_flight_do_not_change_results(ctx, desc):
     d = resized(desc, 96, 64)
     gsc = hpt.Scene(ctx, d, host_bvh=host_tree)
     out = [torch.zeros(96 * 64 * 3, device="cuda", dtype=torch.float32) for _ in range(2)]
+    torch.cuda.synchronize()
     try:
         for spp, per_pass in ((8, 4), (12, 4), (13, 3), (5, 1), (3, 4)):
             ctx.set_passes_in_flight(1)
@@ -297,6 +309,7 @@ def test_passes_in_flight_do_not_change_results(ctx, desc):
             for n in (2, 3, 4):
                 ctx.set_passes_in_flight(n)
                 out[1].fill_(-1.0)
+                torch.cuda.synchronize()      # torch's fill before the library's memset + resolves on another stream
                 b = gsc.render_device(out[1].data_ptr(), want_stats=True, spp=spp, max_depth=8, seed=3, spp_per_pass=per_pass, flags=hpt.RENDER_COUNTERS)
                 torch.cuda.synchronize()
                 assert torch.equal(out[0], out[1]), (spp, per_pass, n)

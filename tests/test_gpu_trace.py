@@ -168,4 +168,24 @@ def test_rejects_malformed_input(ctx, desc):
         sc.trace_rays(0, np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32))
     with pytest.raises(hpt.HptError, match="singular"):
         sc.add_node(-1, 0, -1, -1, np.zeros(9, np.float32), np.zeros(3, np.float32))
+    # scene.rs:330 divides by width and height: an image with exactly one zero dimension panics in the reference
+    import ctypes as C
+    px = np.zeros(15, np.uint8)
+    for w, h in ((0, 5), (5, 0)):
+        assert hpt.lib.hpt_scene_add_image(sc.h, px.ctypes.data_as(hpt.U8P), w, h, None) == -1 and b"zero" in hpt.lib.hpt_last_error()
+    assert hpt.lib.hpt_scene_add_image(sc.h, None, 0, 0, None) == 0      # 0 x 0: the reference's "no data" image (black)
     sc.close()
+
+
+def test_context_destroyed_before_its_scene(desc):
+    """Python's __del__ order at interpreter exit (or a host that frees the context first): the context must stay alive
+    until its last scene is gone -- hpt_context_destroy only marks it then."""
+    import hpt
+    c = hpt.Context(0)
+    sc = hpt.Scene(c)
+    mid = sc.add_mesh(desc.meshes[0], None)
+    sc.commit()
+    c.close()                                         # context first
+    org = np.array([[0, 0, 50]], np.float32); d = np.array([[0, 0, -1]], np.float32)
+    assert sc.trace_rays(mid, org, d)["prim"][0] >= 0 # the scene still works: streams and device are alive
+    sc.close()                                        # frees the context with it
