@@ -91,6 +91,11 @@ struct DInstance {   // one Node with an object, in the reference's DFS visiting
     DXformInv lv[2];              // inline copy of chain levels 0 and 1 (deeper levels: xinv[xf_first + k])
 };
 
+struct DInstBox {    // padded world-space box of an instance (what the TLAS is built over; phase 1 of the instance-list kernel culls with it)
+    float mn[3]; int32_t geom;
+    float mx[3]; int32_t pad;
+};
+
 struct DTexture {
     int32_t kind, image;
     float color[3], color1[3], color2[3];
@@ -121,6 +126,7 @@ struct DScene {
     const float4* trishade;
     const DMesh* meshes;
     const DInstance* instances;
+    const DInstBox* inst_boxes;      // [n_instances]
     const int32_t* mesh_instances;   // indices (into instances[]) of the mesh instances, ascending
     const DXformInv* xinv;
     const DXformFwd* xfwd;

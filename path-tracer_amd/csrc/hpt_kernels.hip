@@ -30,6 +30,12 @@
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
 // lanes of a wave that must hold a leaf of one kind before its block runs (two-level kernel), see DESIGN.md
+#ifndef HPT_PHASE1_CULL
+#define HPT_PHASE1_CULL 0     // instance-list kernel, phase 1: 1 = world-box culling + deferred exact tests (analytic_phase_culled; built, bit-identical,
+#endif                        // measured 21 % SLOWER on the teapot frame -- profiles/r02c_phase1_cull_ab.txt), 0 = every instance exactly at full width
+#ifndef HPT_LDS_TOPCACHE
+#define HPT_LDS_TOPCACHE 0    // A/B variant (profiles/r02c_ldscache_*): the first N Node64 records (breadth-first = top levels) of the tree staged in LDS
+#endif
 #ifndef HPT_PARK_TRI
 #define HPT_PARK_TRI 12
 #endif
@@ -226,7 +232,7 @@ __device__ __forceinline__ bool qbox_hit(const Slab& qs, uint32_t wx, uint32_t w
 // (`ns` must be the quantised slab of the tree's grid for Node32).
 template <bool NODE32>
 __device__ __forceinline__ void test_children(const float4* __restrict__ nodes, int ref, const Slab& ns, float bound_s,
-                                              bool& hitL, bool& hitR, float& tinL, float& tinR, int& l, int& r) {
+                                              bool& hitL, bool& hitR, float& tinL, float& tinR, int& l, int& r, const float4* top = nullptr) {
     if constexpr (NODE32) {
         const uint4* nq = (const uint4*)nodes + (uint32_t)ref * 2u;
         const uint4 q0 = nq[0], q1 = nq[1];
@@ -234,8 +240,12 @@ __device__ __forceinline__ void test_children(const float4* __restrict__ nodes, 
         hitR = qbox_hit(ns, q1.x, q1.y, q1.z, bound_s, tinR);
         l = (int)q0.w; r = (int)q1.w;
     } else {
-        const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS;
-        const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+        float4 q0, q1, q2, q3;
+#if HPT_LDS_TOPCACHE
+        if (top && ref < HPT_LDS_TOPCACHE) { const float4* lq = top + ref * HPT_NODE_QUADS; q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; }
+        else
+#endif
+        { const float4* nq = nodes + (uint32_t)ref * (uint32_t)HPT_NODE_QUADS; q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3]; }
         hitL = box_hit(ns, make_float3(q0.x, q0.y, q0.z), make_float3(q1.x, q1.y, q1.z), bound_s, tinL);
         hitR = box_hit(ns, make_float3(q2.x, q2.y, q2.z), make_float3(q3.x, q3.y, q3.z), bound_s, tinR);
         l = __float_as_int(q0.w); r = __float_as_int(q1.w);
@@ -259,7 +269,9 @@ struct Lds {
     // deferred tests: per lane the best key of the ray it owns (t | triangle, or t | instance | side) + u, v, side of
     // that hit; per wave a pending list of (triangle or instance, owner lane) pairs waiting to be tested 64 at a time
     unsigned long long* best; float* du; float* dv; uint32_t* dsf; uint32_t* ltri; uint8_t* lown;
+    float4* top;         // HPT_LDS_TOPCACHE variant: copy of the first HPT_LDS_TOPCACHE Node64 records
 };
+#define HPT_KEY_NONE 0x7f800000ffffffffull      // key of "no hit": t = +inf, no triangle / instance
 #define HPT_LEAF_CAP 192      // >= 63 left over + 2 appended per lane in one step
 __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -272,6 +284,7 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     L.dsf = (uint32_t*)(L.dv + HPT_BLOCK);
     L.ltri = L.dsf + HPT_BLOCK;
     L.lown = (uint8_t*)(L.ltri + (HPT_BLOCK / 64) * HPT_LEAF_CAP);
+    L.top = (float4*)(((uintptr_t)(L.lown + (HPT_BLOCK / 64) * HPT_LEAF_CAP) + 15) & ~(uintptr_t)15);
     L.refill = 24; L.defer = false;
     return L;
 }
@@ -377,13 +390,63 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
     return false;
 }
 
+// Phase 1 with world-box culling (HPT_PHASE1_CULL = 1; NOT the default, see the measurement below): the whole wave works on one 64-ray piece.  Testing every
+// analytic instance exactly for every ray (analytic_phase above) is 42 multiply-adds of transform chain per level + the
+// 25-instruction test, at full width, although a ray can hit three or four of the instances at most: 55 % of all VALU
+// instructions of k_extend on the teapot frame once the tree was repaired.  Here a ray is first tested against each
+// instance's padded WORLD box (the boxes the TLAS is built over: 12 fma on one slab per ray); (lane, instance) pairs
+// that pass go to the wave's pending list -- free during phase 1: nothing of the traversal is pending then -- and are
+// tested exactly 64 at a time, one pair per lane (test_pending_analytic), merged by the 64-bit LDS min on the key
+// t | instance | side: nearest hit, the earlier instance on equal t (scene.rs:196,251).  Boxes only cull; the exact
+// test is the same code, so hit records are bit-identical (all GPU tests green with it).  A mesh instance's world box
+// stands in for the root-box test (the lane that later pulls the ray tests the local root box anyway).
+// Measured on the teapot frame (A/B of two builds, alternated, profiles/r02c_phase1_cull_ab.txt): exact tests per ray
+// 9 -> 2.7, but k_extend 14.4 -> 17.5 ms per 16 spp: nine slab tests + 2.7 deferred tests (six ds_bpermute, the full
+// chain without the shared level 0, LDS list + atomic) cost more than nine tests in place whose first chain level is
+// shared by the six walls.  Kept as a build variant for scenes with longer instance lists below the TLAS threshold.
+// The lane's own key slot (L.best: the traversal key of the ray it owns) is parked in registers meanwhile.
+template <bool COUNT>
+__device__ __forceinline__ void test_pending_analytic(const DScene& sc, const Lds& L, unsigned first, unsigned n, f3 o, f3 d, unsigned& n_inst);
+template <bool COUNT>
+__device__ __forceinline__ bool analytic_phase_culled(const DScene& sc, const Lds& L, bool valid, f3 o, f3 d, uint32_t slot, Hit& h, uint2& item, unsigned& n_inst) {
+    const unsigned lane = threadIdx.x & 63u, lbase = (threadIdx.x >> 6) * HPT_LEAF_CAP;
+    unsigned long long* key = L.best + threadIdx.x;
+    const unsigned long long parked = *key;
+    *key = HPT_KEY_NONE;
+    const Slab rb = make_raybox(o, d);
+    int mpos = -1, mcount = 0;
+    unsigned pend = 0;      // wave-uniform
+    for (int k = 0; k < sc.n_instances; ++k) {
+        const DInstBox b = load_uniform(sc.inst_boxes, k);      // wave-uniform record: scalar loads
+        float tin;
+        const bool in = valid && box_hit(rb, make_float3(b.mn[0], b.mn[1], b.mn[2]), make_float3(b.mx[0], b.mx[1], b.mx[2]), HPT_INF, tin);
+        if (b.geom == 3) {
+            if (in && mpos < 0) mpos = mcount;
+            mcount++;
+        } else {
+            const unsigned long long m = __ballot(in);
+            if (m) {
+                if (in) L.ltri[lbase + pend + lane_prefix(m)] = (lane << 26) | (uint32_t)k;
+                pend += (unsigned)__popcll(m);
+                if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); }
+            }
+        }
+    }
+    if (pend) test_pending_analytic<COUNT>(sc, L, 0u, pend, o, d, n_inst);
+    const unsigned long long best = *(volatile unsigned long long*)key;
+    *key = parked;
+    h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
+    if ((uint32_t)best != 0xffffffffu) { h.t = __uint_as_float((uint32_t)(best >> 32)); h.inst_side = ((uint32_t)best >> 1) | ((uint32_t)best << 31); }
+    if (mpos >= 0) { item = make_uint2(slot, (uint32_t)mpos); return true; }   // the analytic result travels in hit[slot]
+    return false;
+}
+
 // Deferred triangle tests of one wave: entries [first, first + n) of its pending list, one per lane (n <= 64, uniform).
 // The tester lane fetches the owner lane's mesh-local ray through the LDS crossbar, runs the exact triangle test and
 // merges a hit into the owner's key with a 64-bit LDS min: key = t bits << 32 | triangle, so the minimum is the nearest
 // hit and, on equal t, the lower triangle index (order-independent, hence deterministic; the reference's "later visited wins" depends on its
 // own tree and north_star excludes edge rays).  The lane whose key
 // is the minimum afterwards leaves u, v and the side beside it (LDS operations of one wave execute in order).
-#define HPT_KEY_NONE 0x7f800000ffffffffull      // t = +inf, no triangle
 template <bool COUNT>
 __device__ __forceinline__ void test_pending(const Lds& L, const float4* __restrict__ tris, unsigned first, unsigned n,
                                              f3 lo, f3 ld, unsigned& n_tri) {
@@ -474,18 +537,28 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             const uint32_t i = seg * wv.cap + off0 + lane;
             bool queued = false;
             uint2 item = make_uint2(0, 0);
-            if (off0 + lane < cnt) {
-                if constexpr (LOCAL) {
+            const bool valid = off0 + lane < cnt;
+            if constexpr (LOCAL) {
+                if (valid) {
                     float tin;
                     queued = box_hit(make_raybox(xyz(ray_o[i]), xyz(ray_d[i])), make_float3(lmesh->bmin[0], lmesh->bmin[1], lmesh->bmin[2]),
                                      make_float3(lmesh->bmax[0], lmesh->bmax[1], lmesh->bmax[2]), HPT_INF, tin);
                     item = make_uint2(i, 0u);
                     hit[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); side_out[i] = 0;             // final unless a triangle is hit
-                } else {
+                }
+            } else {
+#if HPT_PHASE1_CULL
+                Hit a;
+                const f3 po = valid ? xyz(ray_o[i]) : mk3(0, 0, 0), pd = valid ? xyz(ray_d[i]) : mk3(0, 0, 1);
+                queued = analytic_phase_culled<COUNT>(sc, L, valid, po, pd, i, a, item, n_inst);      // the whole wave takes part
+                if (valid) { hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side; }   // final for unqueued rays, interim otherwise
+#else
+                if (valid) {
                     Hit a;
                     queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, a, item, n_inst);
                     hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
                 }
+#endif
             }
             const unsigned long long mask = __ballot(queued);
             if (queued) queue[(qn + lane_prefix(mask)) & (QW - 1u)] = item;
@@ -589,7 +662,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             if (ref >= 0) {
                 if (COUNT) n_int++;
                 bool hitL, hitR; float tinL, tinR; int l, r;
-                test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r);
+                test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r, (HPT_LDS_TOPCACHE && !LOCAL && !NODE32) ? L.top : nullptr);
                 cl = hitL ? min(l, 0) : 0; cr = hitR ? min(r, 0) : 0;
                 const bool intL = hitL && l >= 0, intR = hitR && r >= 0;
                 // flat form (two one-level predicated LDS operations instead of a three-level branch nest)
@@ -911,6 +984,13 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
     wv.work = ps.counts + HPT_WORK_COUNTER(depth);
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
+#if HPT_LDS_TOPCACHE
+    if constexpr (!TLAS && !NODE32) {      // (valid for scenes whose first tree holds the records: the one-mesh teapot frame of the A/B)
+        const int n = min(HPT_LDS_TOPCACHE, sc.n_nodes) * HPT_NODE_QUADS;
+        for (int j = threadIdx.x; j < n; j += HPT_BLOCK) L.top[j] = sc.nodes[j];
+        __syncthreads();
+    }
+#endif
     if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     else block_closest_hit<COUNT, NODE32, false, DYN>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     if (COUNT) {
@@ -1356,7 +1436,7 @@ static inline int carve_entries(int stack_entries, bool tlas) { return tlas ? st
 enum { LDS_STACK = 0, LDS_LIST = 1, LDS_TLAS = 2 };
 static inline size_t trav_lds_bytes(int stack_entries, int mode) {
     size_t n = (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16;
-    if (mode == LDS_LIST) n += HPT_QUEUE_CAP * sizeof(uint2) + (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5;
+    if (mode == LDS_LIST) n += HPT_QUEUE_CAP * sizeof(uint2) + (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 + (HPT_LDS_TOPCACHE ? 16 + (size_t)HPT_LDS_TOPCACHE * 64 : 0);
     if (mode == LDS_TLAS) n += (size_t)HPT_BLOCK * 8 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 4;
     return n;
 }

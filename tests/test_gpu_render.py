@@ -154,7 +154,7 @@ def test_render_device_matches_host_entry(ctx, desc):
     st = gsc.render_device(out.data_ptr(), want_stats=True, spp=8, max_depth=8, seed=1, flags=hpt.RENDER_TIME_KERNELS | hpt.RENDER_COUNTERS)
     img = gsc.render(spp=8, max_depth=8, seed=1)["rgb"]
     np.testing.assert_array_equal((out.cpu().numpy().reshape(48, 64, 3) / np.float32(8)), img)
-    assert st.seconds_extend > 0 and st.launches_extend == 9 and st.nodes_visited > 0 and st.inst_tests == 9 * (st.rays_primary + st.rays_bounce)
+    assert st.seconds_extend > 0 and st.launches_extend == 9 and st.nodes_visited > 0 and 0 < st.inst_tests <= 9 * (st.rays_primary + st.rays_bounce)
     gsc.close()
 
 
