@@ -14,7 +14,8 @@ Inputs are resident in HBM before the timed region (the scene is committed once)
 
   python bench.py --config soup|instanced|spheres ...     the other BASELINE.json configs at full size (not the driver's line)
 
-Extra objects on the JSON line: "roofline" (k_extend: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak;
+Extra objects on the JSON line: "roofline" (k_extend, the BVH traversal kernel -- the analytic stage of the extend step,
+k_extend_a, is a launch of its own and shown as analytic_share_of_step: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak;
 the event-bracketed launches are the same K steps run once more on ONE stream, right after the timed region: with two
 passes in flight the event interval of a launch would also cover the other pass's kernels sharing the GPU with it;
 `hbm_physical` / `valu` = the committed rocprofv3 counter passes of the same frame, flagged `stale` when they were
@@ -36,7 +37,11 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-EXTEND_QUEUE_BYTES = 52    # per ray in k_extend itself: ray_o + ray_d read (32 B), hit + hit_inst written (20 B)
+# queue bytes k_extend (the BVH traversal kernel) moves per ray it walks: mesh-queue item 8 B, ray_o + ray_d 32 B, hit + hit_inst
+# read 20 B and written 20 B.  Instance-list scenes walk only the rays that entered a mesh box (stats.rays_mesh); two-level
+# scenes walk every ray in the one kernel (ray 32 B read, hit record 20 B written).
+MESH_QUEUE_BYTES = 80
+TLAS_QUEUE_BYTES = 52
 
 
 def tree_sha256():
@@ -266,7 +271,7 @@ def main():
 
         # kernel timing (rank 0 only; no collective inside): the same K steps on one stream, every launch bracketed by HIP
         # events on the stream it is launched on (HPT_RENDER_TIME_KERNELS) -- the same launches, same rays, serialised
-        ext_s_local = shade_s_local = serial_elapsed = 0.0
+        ext_s_local = ana_s_local = shade_s_local = serial_elapsed = 0.0
         ext_launches = 0
         if rank == 0:
             stream.synchronize(); t1 = time.perf_counter()
@@ -275,6 +280,7 @@ def main():
             stream.synchronize(); serial_elapsed = time.perf_counter() - t1
             assert sum(s.rays_primary + s.rays_bounce for s in kst) == rays_local
             ext_s_local = sum(s.seconds_extend for s in kst)
+            ana_s_local = sum(s.seconds_analytic for s in kst)
             ext_launches = sum(s.launches_extend for s in kst)
             shade_s_local = sum(s.seconds_shade for s in kst)
 
@@ -288,7 +294,9 @@ def main():
         crays = cst.rays_primary + cst.rays_bounce
         info = scene.info()
         inst_bytes = 128.0 * cst.inst_tests if info.uses_tlas else 0.0
-        bytes_per_ray = (info.node_bytes * float(cst.nodes_visited) + 48.0 * cst.tris_tested + inst_bytes) / crays + EXTEND_QUEUE_BYTES
+        walked_frac = 1.0 if info.uses_tlas else cst.rays_mesh / crays      # share of the rays k_extend walks
+        queue_bytes = TLAS_QUEUE_BYTES if info.uses_tlas else MESH_QUEUE_BYTES * walked_frac
+        bytes_per_ray = (info.node_bytes * float(cst.nodes_visited) + 48.0 * cst.tris_tested + inst_bytes) / crays + queue_bytes
         bvh_bytes_per_ray = (info.node_bytes * float(cst.nodes_visited) + 48.0 * cst.tris_tested) / crays
 
     if rank == 0:
@@ -342,7 +350,9 @@ def main():
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(ext_launches),
                          "kernel_timing": "HIP events around every launch of the same %d step(s) re-run on one stream (%.1f ms per step); the timed region keeps %s passes in flight" % (
                              args.steps, serial_elapsed / args.steps * 1e3, args.inflight if args.inflight > 0 else 2),
-                         "extend_share_of_step": round(ext_s_local / serial_elapsed, 3), "shade_share_of_step": round(shade_s_local / serial_elapsed, 3),
+                         "rays_walked_frac": round(walked_frac, 4),
+                         "extend_share_of_step": round(ext_s_local / serial_elapsed, 3), "analytic_share_of_step": round(ana_s_local / serial_elapsed, 3),
+                         "shade_share_of_step": round(shade_s_local / serial_elapsed, 3),
                          "source_sha256": tree_sha256()},
         }
         if world == 1 and tree is not None and not args.no_alt:

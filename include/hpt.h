@@ -106,6 +106,9 @@ typedef struct {
     double seconds_raygen, seconds_extend, seconds_shade, seconds_resolve;   /* HPT_RENDER_TIME_KERNELS (HIP events) */
     uint32_t launches_extend, passes;
     uint64_t samples;                        /* pixel-samples rendered */
+    double seconds_analytic;                 /* HPT_RENDER_TIME_KERNELS: the analytic stage of the extend step (k_extend_a: spheres, planes, mesh
+                                                root boxes; instance-list scenes) -- seconds_extend is the BVH traversal kernel alone */
+    uint64_t rays_mesh;                      /* rays that entered a mesh box = the rays the traversal kernel walked (instance-list scenes) */
 } hpt_render_stats;
 
 typedef struct {
@@ -206,7 +209,7 @@ int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* 
 /* hpt_render_device for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc.  No counterpart in the reference (its main.rs:55 allocates the frame buffer per run).  Same
  * arguments, same kernels and bit-identical output as hpt_render_device, but the pass buffers (wavefront queues, hit and
- * radiance records, counters, Halton table) come from a static device array of HPT_NOALLOC_SCRATCH_MB (72) MB that each
+ * radiance records, counters, Halton table) come from a static device array of HPT_NOALLOC_SCRATCH_MB (77) MB that each
  * GPU the library runs on holds until the process ends, instead of from hipMalloc: the call allocates nothing (no
  * hipMalloc / hipFree, no stream or event creation).  Limits (HPT_ERR_LIMIT beyond them): the frame has at most
  * HPT_NOALLOC_MAX_PIXELS = 2^19 pixels (the reference's 800 x 600 fits) and a call renders at most HPT_NOALLOC_MAX_SPP =
@@ -215,7 +218,7 @@ int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* 
  * scene): calls that overlap on one GPU race -- serialise them. */
 #define HPT_NOALLOC_MAX_PIXELS (1u << 19)
 #define HPT_NOALLOC_MAX_SPP 4096
-#define HPT_NOALLOC_SCRATCH_MB 72
+#define HPT_NOALLOC_SCRATCH_MB 77
 int hpt_render_device_noalloc(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
                               hpt_render_stats* stats);
 /* One round of the adaptive loop (main.rs:72-99 restricted to a sample range) on DEVICE buffers, for hosts that

@@ -67,7 +67,7 @@ struct hpt_context {
     hipStream_t aux_stream[HPT_MAX_INFLIGHT - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_done[HPT_MAX_INFLIGHT] = {};
     int overlap = 2;            // passes in flight (1 = one stream)
-    int extend_spare = 1;       // k_extend workgroup slots per CU left to the other pass when two are in flight
+    int extend_spare = 2;       // k_extend workgroup slots per CU left to the other pass when two are in flight (6 resident -> a grid of 4 per CU)
     int num_cus = 256;
     int max_blocks = 2048;
     int extend_blocks = 1024;   // persistent grid of the test-entry traversal kernels
@@ -107,12 +107,13 @@ struct hpt_scene {
     int n_xf = 0, n_mat = 0;
     HptkPlan plan;              // launch configuration of this scene's kernels (hpt_scene_commit)
     int shade_grid = 0;         // k_shade workgroups per launch
+    int analytic_grid = 0;      // k_extend_a workgroups per launch
     int32_t tlas_nodes = 0, node_bytes = 64, trees_optimized = 0; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
-    DevBuf w_q[2][3], w_hit, w_hit_inst, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
-    struct PassBufs { DevBuf q[2][3], hit, hit_inst, radiance, counts; } x[HPT_MAX_INFLIGHT - 1];   // pass buffers of the further passes in flight
+    DevBuf w_q[2][3], w_hit, w_hit_inst, w_mq, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
+    struct PassBufs { DevBuf q[2][3], hit, hit_inst, mq, radiance, counts; } x[HPT_MAX_INFLIGHT - 1];   // pass buffers of the further passes in flight
     // trace workspace
-    DevBuf t_org, t_dir, t_hit, t_side, t_misc[9];
+    DevBuf t_org, t_dir, t_hit, t_side, t_misc[9], t_mq, t_mqcount;
 };
 
 static void identity_tex(hpt_texture& t) {   // load.rs:30-34
@@ -265,13 +266,13 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     for (hipStream_t a : s->ctx->aux_stream) if (a) (void)hipStreamSynchronize(a);   // (joined already unless a render failed half way)
     DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_instboxes, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_materials,
-                     &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
+                     &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_mq, &s->t_mq, &s->t_mqcount, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
                      &s->w_accum, &s->w_minmax, &s->w_spp, &s->w_list[0], &s->w_list[1], &s->w_listcount, &s->w_out,
                      &s->t_org, &s->t_dir, &s->t_hit, &s->t_side};
     for (DevBuf* b : all) b->release();
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) s->w_q[a][k].release();
     for (auto& x : s->x) {
-        x.hit.release(); x.hit_inst.release(); x.radiance.release(); x.counts.release();
+        x.hit.release(); x.hit_inst.release(); x.mq.release(); x.radiance.release(); x.counts.release();
         for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) x.q[a][k].release();
     }
     for (DevBuf& b : s->t_misc) b.release();
@@ -663,6 +664,8 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     // k_shade: two rounds of exactly the resident workgroups (5/CU -> 10/CU measured best: 8/CU +3 %, 4/CU +8 %)
     s->shade_grid = s->plan.shade_per_cu > 0 ? ctx->num_cus * s->plan.shade_per_cu * 2 : ctx->max_blocks;
     if (const char* e = getenv("HPT_SHADE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) s->shade_grid = ctx->num_cus * v; }
+    s->analytic_grid = s->plan.analytic_per_cu > 0 ? ctx->num_cus * s->plan.analytic_per_cu * 2 : ctx->max_blocks;      // (4 / 8 / 16 per CU with two passes in flight: 13.47 / 13.62 / 14.05 Grays/s)
+    if (const char* e = getenv("HPT_ANALYTIC_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) s->analytic_grid = ctx->num_cus * v; }
     s->committed = true; s->generation++;
     return HPT_OK;
 }
@@ -695,8 +698,12 @@ extern "C" int hpt_trace_rays_device(hpt_scene* s, int32_t mesh_id, int64_t n, c
         e0 = ctx->events[0]; e1 = ctx->events[1];
         HIPCHK(hipEventRecord(e0, st));
     }
+    // mesh queue of the root-box pass: items for one 2^30-ray launch at a time, one counter (its own 128-B line) per launch
+    const size_t launches = (size_t)((n + (1ll << 30) - 1) >> 30);
+    CHK(s->t_mq.ensure(hptk_mq_slots((uint64_t)std::min<int64_t>(n, 1ll << 30)) * 8)); CHK(s->t_mqcount.ensure(launches * HPT_COUNTS_PER_DEPTH * 4));
+    HIPCHK(hipMemsetAsync(s->t_mqcount.p, 0, launches * HPT_COUNTS_PER_DEPTH * 4, st));
     hptk_trace_rays(st, ctx->extend_blocks, s->ds, s->h_meshes[mesh_id], n, (const float4*)org4, (const float4*)dir4, (float4*)hit4, (uint8_t*)side_out,
-                    count_visits != 0, d_stat);
+                    count_visits != 0, d_stat, s->t_mq.as<uint2>(), s->t_mqcount.as<uint32_t>());
     HIPCHK(hipGetLastError());
     if (stats) {
         HIPCHK(hipEventRecord(e1, st));
@@ -766,12 +773,14 @@ extern "C" int hpt_scene_intersect(hpt_scene* s, int64_t n, const float* org3, c
     CHK(s->t_org.ensure(N * 16)); CHK(s->t_dir.ensure(N * 16));
     const size_t sizes[9] = {N * 4, N * 4, N * 4, N, N * 16, N * 16, N * 16, N * 16, N * 4};
     for (int k = 0; k < 9; ++k) CHK(s->t_misc[k].ensure(sizes[k]));
+    CHK(s->t_mq.ensure(hptk_mq_slots(N) * 8)); CHK(s->t_mqcount.ensure((size_t)HPT_COUNTS_PER_DEPTH * 4));
+    HIPCHK(hipMemsetAsync(s->t_mqcount.p, 0, (size_t)HPT_COUNTS_PER_DEPTH * 4, st));
     HIPCHK(hipMemcpyAsync(s->t_org.p, o4.data(), N * 16, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(s->t_dir.p, d4.data(), N * 16, hipMemcpyHostToDevice, st));
     hptk_scene_intersect(st, ctx->extend_blocks, s->stack_entries, s->ds, n, s->t_org.as<float4>(), s->t_dir.as<float4>(), s->t_misc[7].as<float4>(),
                          s->t_misc[8].as<uint32_t>(), s->t_misc[0].as<int>(),
                          s->t_misc[1].as<int>(), s->t_misc[2].as<float>(), s->t_misc[3].as<uint8_t>(), s->t_misc[4].as<float4>(),
-                         s->t_misc[5].as<float4>(), s->t_misc[6].as<float4>());
+                         s->t_misc[5].as<float4>(), s->t_misc[6].as<float4>(), s->t_mq.as<uint2>(), s->t_mqcount.as<uint32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     if (node) HIPCHK(hipMemcpy(node, s->t_misc[0].p, N * 4, hipMemcpyDeviceToHost));
@@ -806,8 +815,8 @@ struct EventLog {   // HPT_RENDER_TIME_KERNELS: (kind, start, stop) triples from
         used += 2;
         return HPT_OK;
     }
-    int collect(double out[4], uint32_t* n_extend) {
-        for (int k = 0; k < 4; ++k) out[k] = 0.0;
+    int collect(double out[5], uint32_t* n_extend) {
+        for (int k = 0; k < 5; ++k) out[k] = 0.0;
         for (const Rec& r : recs) {
             float ms = 0.0f;
             HIPCHK(hipEventElapsedTime(&ms, ctx->events[r.a], ctx->events[r.b]));
@@ -860,8 +869,12 @@ static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool c
     const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
     const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
     const int sblocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)s->shade_grid);
+    const int ablocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)s->analytic_grid);
     for (int depth = 0; depth <= ps.max_depth; ++depth) {
-        CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st));
+        if (!s->ds.use_tlas) {      // instance-list path: analytic stage over every ray, then the traversal over the rays that entered a mesh box
+            CHK(ev.begin(4, st)); hptk_extend_analytic(st, ablocks, s->ds, ps, depth, counters); CHK(ev.end(st));
+            if (s->ds.n_mesh_instances > 0) { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
+        } else { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
         CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->plan, s->ds, ps, depth, s->n_xf, s->n_mat); CHK(ev.end(st));
     }
     if (after) HIPCHK(hipStreamWaitEvent(st, after, 0));
@@ -880,14 +893,15 @@ static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps, int 
     if (n_paths >= (1ull << 31) - (1ull << 20)) return fail(HPT_ERR_LIMIT, "render: more than 2^31 paths per pass; lower spp_per_pass");
     const uint64_t max_paths = (uint64_t)shard_cap_for(n_paths) * HPT_SHARDS;   // slots of a sharded queue
     DevBuf (&q)[2][3] = set ? s->x[set - 1].q : s->w_q;
-    DevBuf &hit = set ? s->x[set - 1].hit : s->w_hit, &hit_inst = set ? s->x[set - 1].hit_inst : s->w_hit_inst,
+    DevBuf &hit = set ? s->x[set - 1].hit : s->w_hit, &hit_inst = set ? s->x[set - 1].hit_inst : s->w_hit_inst, &mq = set ? s->x[set - 1].mq : s->w_mq,
            &radiance = set ? s->x[set - 1].radiance : s->w_radiance, &counts = set ? s->x[set - 1].counts : s->w_counts;
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(q[a][k].ensure(max_paths * 16));
     CHK(hit.ensure(max_paths * 16)); CHK(hit_inst.ensure(max_paths * 4)); CHK(radiance.ensure(max_paths * 16));
+    if (!s->ds.use_tlas && s->ds.n_mesh_instances > 0) CHK(mq.ensure(max_paths * 8));      // mesh queue of the instance-list path
     CHK(counts.ensure((size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = q[a][0].as<float4>(); ps.q[a].ray_d = q[a][1].as<float4>(); ps.q[a].thr = q[a][2].as<float4>(); }
-    ps.hit = hit.as<float4>(); ps.hit_inst = hit_inst.as<uint32_t>(); ps.radiance = radiance.as<float4>();
+    ps.hit = hit.as<float4>(); ps.hit_inst = hit_inst.as<uint32_t>(); ps.mq = mq.as<uint2>(); ps.radiance = radiance.as<float4>();
     ps.counts = counts.as<uint32_t>(); ps.stat = s->w_stat.as<unsigned long long>();
     return HPT_OK;
 }
@@ -985,9 +999,10 @@ static int finish_stats(hpt_scene* s, hpt_render_stats* stats, EventLog& ev, dou
     HIPCHK(hipMemcpy(h, d_stat ? d_stat : s->w_stat.p, sizeof h, hipMemcpyDeviceToHost));
     stats->rays_primary = h[4]; stats->rays_bounce = h[0] - h[4];
     stats->nodes_visited = h[1]; stats->tris_tested = h[2]; stats->inst_tests = h[3];
-    double k[4];
+    stats->rays_mesh = h[5];
+    double k[5];
     CHK(ev.collect(k, &stats->launches_extend));
-    stats->seconds_raygen = k[0]; stats->seconds_extend = k[1]; stats->seconds_shade = k[2]; stats->seconds_resolve = k[3];
+    stats->seconds_raygen = k[0]; stats->seconds_extend = k[1]; stats->seconds_shade = k[2]; stats->seconds_resolve = k[3]; stats->seconds_analytic = k[4];
     stats->seconds_total = now_s() - t0;
     return HPT_OK;
 }
@@ -1041,7 +1056,7 @@ extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* 
         ps.q[a].thr = (float4*)(base + HPT_NOALLOC_OFF_Q(3 * a + 2));
     }
     ps.hit = (float4*)(base + HPT_NOALLOC_OFF_HIT); ps.radiance = (float4*)(base + HPT_NOALLOC_OFF_RADIANCE);
-    ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
+    ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.mq = (uint2*)(base + HPT_NOALLOC_OFF_MQ); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
     ps.stat = (unsigned long long*)(base + HPT_NOALLOC_OFF_STAT);
     float2* d_halton = (float2*)(base + HPT_NOALLOC_OFF_HALTON);
     // the array keeps the last call's contents: statistics start at zero here, counters and radiance per pass (run_pass)

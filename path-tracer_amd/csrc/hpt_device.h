@@ -36,8 +36,11 @@
 #define HPT_COUNTS_PER_DEPTH (HPT_SHARDS * HPT_COUNT_STRIDE)
 // DPass.counts holds HPT_MAX_DEPTH_LIMIT + 2 blocks of append counters, then one work counter per depth (k_extend hands
 // its input out in batches of HPT_PIECE_BATCH 64-ray pieces), HPT_COUNT_STRIDE apart like the others
-#define HPT_COUNTS_TOTAL ((HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNTS_PER_DEPTH + (HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNT_STRIDE)
+// ... then one block of append counters per depth for the MESH QUEUE (k_extend_a appends the rays that enter a mesh box,
+// k_extend walks them), laid out like the path-queue counters
 #define HPT_WORK_COUNTER(depth) ((HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNTS_PER_DEPTH + (depth) * HPT_COUNT_STRIDE)
+#define HPT_MQ_COUNTS(depth) ((HPT_MAX_DEPTH_LIMIT + 2) * (HPT_COUNTS_PER_DEPTH + HPT_COUNT_STRIDE) + (depth) * HPT_COUNTS_PER_DEPTH)
+#define HPT_COUNTS_TOTAL ((HPT_MAX_DEPTH_LIMIT + 2) * (2 * HPT_COUNTS_PER_DEPTH + HPT_COUNT_STRIDE))
 #ifndef HPT_PIECE_BATCH
 #define HPT_PIECE_BATCH 8
 #endif
@@ -55,12 +58,13 @@
 // queue slots: 64 segments, each rounded up to whole 256-path chunks
 #define HPT_NOALLOC_SLOTS ((size_t)HPT_NOALLOC_MAX_PATHS + (size_t)HPT_SHARDS * HPT_BLOCK)
 #define HPT_ALIGN256(x) (((size_t)(x) + 255) & ~(size_t)255)
-// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), counters, statistics, Halton
+// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), mesh queue (8 B), counters, statistics, Halton
 #define HPT_NOALLOC_OFF_Q(k) ((size_t)(k) * HPT_ALIGN256(HPT_NOALLOC_SLOTS * 16))
 #define HPT_NOALLOC_OFF_HIT HPT_NOALLOC_OFF_Q(6)
 #define HPT_NOALLOC_OFF_RADIANCE HPT_NOALLOC_OFF_Q(7)
 #define HPT_NOALLOC_OFF_HIT_INST HPT_NOALLOC_OFF_Q(8)
-#define HPT_NOALLOC_OFF_COUNTS (HPT_NOALLOC_OFF_HIT_INST + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 4))
+#define HPT_NOALLOC_OFF_MQ (HPT_NOALLOC_OFF_HIT_INST + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 4))
+#define HPT_NOALLOC_OFF_COUNTS (HPT_NOALLOC_OFF_MQ + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 8))
 #define HPT_NOALLOC_OFF_STAT (HPT_NOALLOC_OFF_COUNTS + HPT_ALIGN256((size_t)HPT_COUNTS_TOTAL * 4))
 #define HPT_NOALLOC_OFF_HALTON (HPT_NOALLOC_OFF_STAT + 256)
 #define HPT_NOALLOC_SCRATCH_BYTES (HPT_NOALLOC_OFF_HALTON + HPT_ALIGN256((size_t)HPT_NOALLOC_MAX_SPP * 8))
@@ -152,6 +156,7 @@ struct DPass {
     DQueue q[2];
     float4* hit;         // (t, u, v, as_float(global tri or -1))
     uint32_t* hit_inst;  // instance | side<<31, HPT_MISS_INST on miss
+    uint2* mq;           // mesh queue of the current depth: (slot, first mesh instance to visit) of the rays that entered a mesh box, sharded like the path queues
     float4* radiance;    // (L.rgb, 0) of sample s of slot i at [s * n_slots + i] (k_resolve reads it coalesced); zeroed by the pass
     uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2][HPT_SHARDS] live paths per depth and queue segment, HPT_COUNT_STRIDE apart
     uint32_t shard_cap;  // slots per segment (multiple of HPT_BLOCK); a queue holds HPT_SHARDS * shard_cap slots
@@ -162,5 +167,5 @@ struct DPass {
     uint32_t first_sample;       // Halton index of sample s is first_sample + s + 1
     uint32_t seed;
     int32_t max_depth;
-    unsigned long long* stat;    // [0] rays, [1] nodes, [2] tris, [3] inst tests, [4] primary rays
+    unsigned long long* stat;    // [0] rays, [1] nodes, [2] tris, [3] inst tests, [4] primary rays, [5] rays that entered a mesh box
 };

@@ -22,7 +22,7 @@
 #define PI_F 3.14159265358979323846f
 // register budgets (waves per SIMD the allocator must reach) of the two hot kernels; see DESIGN.md tuning log
 #ifndef HPT_EXTEND_WAVES
-#define HPT_EXTEND_WAVES 5       // instance-list kernel: 85 VGPRs, 5 workgroups per CU by its 31.5 KB of LDS; the two-level kernel (101..118 VGPRs) stays at 4
+#define HPT_EXTEND_WAVES 6       // mesh-queue traversal kernel: 71 VGPRs, 6 workgroups per CU by its 25.5 KB of LDS (18 stack entries); the two-level kernel (101..118 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 7
@@ -30,9 +30,6 @@
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
 #define HPT_INF __builtin_inff()
 // lanes of a wave that must hold a leaf of one kind before its block runs (two-level kernel), see DESIGN.md
-#ifndef HPT_PHASE1_CULL
-#define HPT_PHASE1_CULL 0     // instance-list kernel, phase 1: 1 = world-box culling + deferred exact tests (analytic_phase_culled; built, bit-identical,
-#endif                        // measured 21 % SLOWER on the teapot frame -- profiles/r02c_phase1_cull_ab.txt), 0 = every instance exactly at full width
 #ifndef HPT_LDS_TOPCACHE
 #define HPT_LDS_TOPCACHE 0    // A/B variant (profiles/r02c_ldscache_*): the first N Node64 records (breadth-first = top levels) of the tree staged in LDS
 #endif
@@ -112,12 +109,30 @@ __device__ __forceinline__ f3 to_local(const DXformInv& X, f3 v) {
     f3 w = mk3(v.x - X.r0[3], v.y - X.r1[3], v.z - X.r2[3]);
     return mk3(rowdot(X.r0, w), rowdot(X.r1, w), rowdot(X.r2, w));
 }
-// scene.rs:228-232 for one level
+// scene.rs:228-232 for one level: lp = to_local(pos), lq = to_local(pos + dir), dir' = lq - lp.
+// The two to_local evaluations are the same 18 operations on two points, so they run as PAIRS (p, q) per component in
+// packed f32 arithmetic (v_pk_add_f32 / v_pk_mul_f32: two IEEE operations per lane and instruction at the issue rate of
+// one -- scripts/micro/pk_f32.hip: 72.9 vs 38.7 T operations/s on MI355X).  Every component sees exactly the operations
+// and the order of to_local() above (no contraction: -ffp-contract=off), so the result is bit-identical.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef HPT_PACKED_CHAIN
+#define HPT_PACKED_CHAIN 1
+#endif
 __device__ __forceinline__ void ray_level(const DXformInv& X, f3& o, f3& d) {
+#if HPT_PACKED_CHAIN
+    v2f x = {o.x, o.x + d.x}, y = {o.y, o.y + d.y}, z = {o.z, o.z + d.z};
+    x = x - X.r0[3]; y = y - X.r1[3]; z = z - X.r2[3];
+    const v2f lx = (X.r0[0] * x + X.r0[1] * y) + X.r0[2] * z;
+    const v2f ly = (X.r1[0] * x + X.r1[1] * y) + X.r1[2] * z;
+    const v2f lz = (X.r2[0] * x + X.r2[1] * y) + X.r2[2] * z;
+    o = mk3(lx.x, ly.x, lz.x);
+    d = mk3(lx.y - lx.x, ly.y - ly.x, lz.y - lz.x);
+#else
     f3 lp = to_local(X, o);
     f3 lq = to_local(X, add3(o, d));
     d = sub3(lq, lp);
     o = lp;
+#endif
 }
 // levels 1.. of an instance's chain (level 0 is applied by the caller so that siblings can share it)
 __device__ __forceinline__ void ray_rest_levels(const DScene& sc, const DInstance& in, f3& o, f3& d) {
@@ -256,14 +271,14 @@ struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 
 // ---- workgroup-local LDS layout of the traversal kernels (dynamic shared memory) ----
 // instance-list path (k_extend, k_trace_rays, k_scene_closest without a TLAS):
-//   [stack: stack_entries x HPT_BLOCK ints][16 B pad][rings: one per wave, HPT_QUEUE_CAP uint2 in all]
+//   [stack: stack_entries x HPT_BLOCK ints][16 B pad]
 //   [best: HPT_BLOCK keys][du, dv, dsf: HPT_BLOCK words each][ltri: per wave HPT_LEAF_CAP words][lown: per wave HPT_LEAF_CAP bytes]
 // two-level path: [stack][16 B pad] and, when analytic instances are deferred, [best][ltri]
 // (an LDS copy of the top tree levels was tried twice -- 16..1024 nodes -- and was 5 % slower each time: the second, LDS-side
 //  wait per step costs more than the fetches it saves)
 struct Lds {
     int* stack;          // per-lane traversal stack, lane's column = stack + threadIdx.x, stride HPT_BLOCK
-    uint2* queue;        // ray rings (slot, first mesh instance to visit)
+    uint2* queue;        // (unused since the analytic stage became a launch of its own: rays come from the mesh queue in global memory)
     int refill;          // idle lanes at which a wave leaves its traversal loop to refill
     bool defer;          // two-level path: analytic instances go through the pending list
     // deferred tests: per lane the best key of the ray it owns (t | triangle, or t | instance | side) + u, v, side of
@@ -272,13 +287,13 @@ struct Lds {
     float4* top;         // HPT_LDS_TOPCACHE variant: copy of the first HPT_LDS_TOPCACHE Node64 records
 };
 #define HPT_KEY_NONE 0x7f800000ffffffffull      // key of "no hit": t = +inf, no triangle / instance
-#define HPT_LEAF_CAP 192      // >= 63 left over + 2 appended per lane in one step
+#define HPT_LEAF_CAP 128      // >= 63 left over + 64 appended (one child side of a step; a batch is tested between the two sides)
 __device__ __forceinline__ Lds lds_carve(int stack_entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L;
     L.stack = (int*)lds_raw;
-    L.queue = (uint2*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16);
-    L.best = (unsigned long long*)(L.queue + HPT_QUEUE_CAP);
+    L.queue = nullptr;
+    L.best = (unsigned long long*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16);
     L.du = (float*)(L.best + HPT_BLOCK);
     L.dv = L.du + HPT_BLOCK;
     L.dsf = (uint32_t*)(L.dv + HPT_BLOCK);
@@ -293,7 +308,7 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries) {
 __device__ __forceinline__ Lds lds_carve_tlas(int stack_entries, bool defer) {
     Lds L = lds_carve(stack_entries);
     L.defer = defer;
-    L.best = (unsigned long long*)L.queue;      // no rings on this path
+    L.best = (unsigned long long*)((unsigned char*)L.stack + (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16);
     L.ltri = (uint32_t*)(L.best + HPT_BLOCK);
     return L;
 }
@@ -390,55 +405,42 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
     return false;
 }
 
-// Phase 1 with world-box culling (HPT_PHASE1_CULL = 1; NOT the default, see the measurement below): the whole wave works on one 64-ray piece.  Testing every
-// analytic instance exactly for every ray (analytic_phase above) is 42 multiply-adds of transform chain per level + the
-// 25-instruction test, at full width, although a ray can hit three or four of the instances at most: 55 % of all VALU
-// instructions of k_extend on the teapot frame once the tree was repaired.  Here a ray is first tested against each
-// instance's padded WORLD box (the boxes the TLAS is built over: 12 fma on one slab per ray); (lane, instance) pairs
-// that pass go to the wave's pending list -- free during phase 1: nothing of the traversal is pending then -- and are
-// tested exactly 64 at a time, one pair per lane (test_pending_analytic), merged by the 64-bit LDS min on the key
-// t | instance | side: nearest hit, the earlier instance on equal t (scene.rs:196,251).  Boxes only cull; the exact
-// test is the same code, so hit records are bit-identical (all GPU tests green with it).  A mesh instance's world box
-// stands in for the root-box test (the lane that later pulls the ray tests the local root box anyway).
-// Measured on the teapot frame (A/B of two builds, alternated, profiles/r02c_phase1_cull_ab.txt): exact tests per ray
-// 9 -> 2.7, but k_extend 14.4 -> 17.5 ms per 16 spp: nine slab tests + 2.7 deferred tests (six ds_bpermute, the full
-// chain without the shared level 0, LDS list + atomic) cost more than nine tests in place whose first chain level is
-// shared by the six walls.  Kept as a build variant for scenes with longer instance lists below the TLAS threshold.
-// The lane's own key slot (L.best: the traversal key of the ray it owns) is parked in registers meanwhile.
+// The analytic stage of the instance-list path as a launch of its own (k_extend_a, k_scene_analytic): one thread per ray,
+// streaming, at the occupancy a 48-register kernel without LDS gets.  Round 1 ran this as "phase 1" inside the persistent
+// traversal kernel; measured on the teapot frame it was 38 % of that kernel's time and LATENCY-bound there -- five waves
+// per SIMD (the traversal's registers and LDS) cannot hide the ray loads and nine scalar record loads per piece: the same
+// code took 8.9 / 7.0 / 6.0 / 5.5 ms at 2 / 3 / 4 / 5 workgroups per CU, and packing its arithmetic (25 % fewer VALU
+// instructions) changed nothing.  Writes hit[] / hit_inst[] of EVERY ray (final for rays that enter no mesh box) and
+// appends the others to the mesh queue, sharded like the path queues (a ray stays in the segment it came from):
+// ballot + wave prefix + one atomic per wave.  (World-box culling of the instance list with deferred exact tests was
+// built and measured in round 2 -- commit c4bf446's successor, profiles/r02c_phase1_cull_ab.txt: exact tests per ray
+// 9 -> 2.7, kernel 21 % slower; not kept.)
 template <bool COUNT>
-__device__ __forceinline__ void test_pending_analytic(const DScene& sc, const Lds& L, unsigned first, unsigned n, f3 o, f3 d, unsigned& n_inst);
-template <bool COUNT>
-__device__ __forceinline__ bool analytic_phase_culled(const DScene& sc, const Lds& L, bool valid, f3 o, f3 d, uint32_t slot, Hit& h, uint2& item, unsigned& n_inst) {
-    const unsigned lane = threadIdx.x & 63u, lbase = (threadIdx.x >> 6) * HPT_LEAF_CAP;
-    unsigned long long* key = L.best + threadIdx.x;
-    const unsigned long long parked = *key;
-    *key = HPT_KEY_NONE;
-    const Slab rb = make_raybox(o, d);
-    int mpos = -1, mcount = 0;
-    unsigned pend = 0;      // wave-uniform
-    for (int k = 0; k < sc.n_instances; ++k) {
-        const DInstBox b = load_uniform(sc.inst_boxes, k);      // wave-uniform record: scalar loads
-        float tin;
-        const bool in = valid && box_hit(rb, make_float3(b.mn[0], b.mn[1], b.mn[2]), make_float3(b.mx[0], b.mx[1], b.mx[2]), HPT_INF, tin);
-        if (b.geom == 3) {
-            if (in && mpos < 0) mpos = mcount;
-            mcount++;
-        } else {
-            const unsigned long long m = __ballot(in);
-            if (m) {
-                if (in) L.ltri[lbase + pend + lane_prefix(m)] = (lane << 26) | (uint32_t)k;
-                pend += (unsigned)__popcll(m);
-                if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); }
-            }
+__device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView& wv, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                               float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, uint2* __restrict__ mq,
+                                               uint32_t* __restrict__ mq_counts, uint32_t mq_shards, uint32_t mq_cap, unsigned& n_inst, unsigned& n_queued) {
+    const unsigned lane = threadIdx.x & 63u;
+    const uint32_t total = input_pieces(wv) / (HPT_BLOCK / 64);      // 256-slot chunks up to the fullest segment
+    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+        uint32_t i;
+        const bool valid = work_slot(wv, w, i);
+        const uint32_t seg = w % mq_shards;      // (render: the segment the ray came from; one atomic counter per segment: a single one serialises)
+        bool queued = false;
+        uint2 item = make_uint2(0, 0);
+        if (valid) {
+            Hit a;
+            queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, a, item, n_inst);
+            hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
+        }
+        const unsigned long long mask = __ballot(queued);
+        if (mask) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&mq_counts[seg * HPT_COUNT_STRIDE], (uint32_t)__popcll(mask));
+            wbase = __shfl(wbase, 0);
+            if (queued) mq[seg * mq_cap + wbase + lane_prefix(mask)] = item;
+            if (lane == 0) n_queued += (unsigned)__popcll(mask);
         }
     }
-    if (pend) test_pending_analytic<COUNT>(sc, L, 0u, pend, o, d, n_inst);
-    const unsigned long long best = *(volatile unsigned long long*)key;
-    *key = parked;
-    h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
-    if ((uint32_t)best != 0xffffffffu) { h.t = __uint_as_float((uint32_t)(best >> 32)); h.inst_side = ((uint32_t)best >> 1) | ((uint32_t)best << 31); }
-    if (mpos >= 0) { item = make_uint2(slot, (uint32_t)mpos); return true; }   // the analytic result travels in hit[slot]
-    return false;
 }
 
 // Deferred triangle tests of one wave: entries [first, first + n) of its pending list, one per lane (n <= 64, uniform).
@@ -478,45 +480,48 @@ __device__ __forceinline__ void test_pending(const Lds& L, const float4* __restr
     }
 }
 
-// Closest hit over the rays of a (sharded) queue (scene.rs:190-208).  Every WAVE is a persistent worker of its own (no
-// workgroup barrier anywhere): it takes 64-ray pieces of the input (piece x = quarter x % 4 of chunk x / 4, pieces
-// x = global wave, + number of waves, ...) and alternates between two kinds of work.
-//  phase 1 (all 64 lanes, uniform control flow): every analytic instance (sphere / plane) in visiting order, plus the
-//          root-box test of the first mesh instance the ray enters; such a ray is appended to the wave's LDS queue
-//          (ring of HPT_QUEUE_CAP / 4 = 128 items) instead of being traversed; runs whenever fewer than 64 rays are queued
-//  phase 2 (persistent lanes): a lane owns one queued ray at a time: it walks the BVHs of the mesh instances that ray
-//          still has to visit (trace order = visiting order) and writes the final hit record.  The inner loop is
-//          nothing but box steps: a child that is a leaf and whose box the ray enters is not walked into but appended
-//          to the wave's pending list (triangle, owner lane), and as soon as 64 are pending the whole wave tests them,
-//          one pair per lane (test_pending) -- one-triangle leaves reach a wave at ~4 per step, so testing them in
-//          place ran the 90-instruction triangle block at 7 % lane utilisation in every step.  The owner's culling
-//          bound is refreshed from its key after each batch (a stale bound only costs visits, never a hit).  The wave
-//          leaves the inner loop as soon as L.refill lanes have finished their mesh, tests what is still pending,
-//          merges the results and hands the idle lanes the next queued rays.
-// Rays in flight stay in their lanes across phase 1, so the only under-filled steps of a wave are the ones at the very
-// end of the launch (node visits per ray are heavy-tailed, 20..300: when the queue was drained to the last ray before
+// Closest hit of the rays in a MESH QUEUE (scene.rs:190-208; bvh.rs:148-204, geometry.rs:132-221): items (slot, first
+// mesh instance to visit) that the analytic stage of the same depth -- a launch of its own: block_analytic, or the
+// root-box pass of the Mesh::intersect entry -- appended for the rays that enter a mesh box.  hit[] / hit_inst[] already
+// hold each ray's best analytic hit; this launch brings them up to date.
+// Every WAVE is a persistent worker of its own (no workgroup barrier anywhere): it takes 64-item pieces of the queue
+// (piece x = quarter x % 4 of chunk x / 4; pieces x = global wave, + number of waves, ..., or through the launch's work
+// counter when DYNAMIC) and hands their items to lanes as they fall idle.
+//  persistent lanes: a lane owns one ray at a time: it walks the BVHs of the mesh instances that ray still has to
+//          visit (trace order = visiting order) and writes the final hit record.  The inner loop is nothing but box
+//          steps: a child that is a leaf and whose box the ray enters is not walked into but appended to the wave's
+//          pending list (triangle, owner lane), and as soon as 64 are pending the whole wave tests them, one pair per
+//          lane (test_pending) -- one-triangle leaves reach a wave at ~4 per step, so testing them in place ran the
+//          90-instruction triangle block at 7 % lane utilisation in every step.  The owner's culling bound is refreshed
+//          from its key after each batch (a stale bound only costs visits, never a hit).  The wave leaves the inner
+//          loop as soon as L.refill lanes have finished their mesh, tests what is still pending, merges the results
+//          and hands the idle lanes the next items.
+// Rays in flight stay in their lanes across refills, so the only under-filled steps of a wave are the ones at the very
+// end of the launch (node visits per ray are heavy-tailed, 20..300: when the input was drained to the last ray before
 // each refill -- the first version -- every drain ended in such a tail and half of all lane-steps were idle).
-// Rays are identified by their slot i; results go to hit[i] / hit_inst[i] exactly once per ray.
-// LOCAL (the Mesh::intersect test entry, k_trace_rays): rays are given in the space of ONE mesh, `lmesh`; phase 1 is its
-// root-box test alone, and the result is hit[i] = (t, u, v, triangle index inside the mesh | -1), side_out[i].
-// DYNAMIC: the launch has a work counter (wv.work, zeroed beforehand) and input pieces are handed out through it.
+// Rays are identified by their slot i; results go to hit[i] / hit_inst[i].
+// LOCAL (the Mesh::intersect test entry, k_trace_rays): rays are given in the space of ONE mesh, `lmesh`; the result is
+// hit[i] = (t, u, v, triangle index inside the mesh | -1), side_out[i].
+// (Round 1 ran the analytic stage inside this kernel, feeding a per-wave LDS ring; as a launch of its own it runs at 8
+//  waves per SIMD instead of 5 -- it was latency-bound here -- and this kernel shed 23 registers and 5.3 KB of LDS: 6
+//  workgroups per CU instead of 5.)
 template <bool COUNT, bool NODE32, bool LOCAL = false, bool DYNAMIC = false>
-__device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
+__device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const uint2* __restrict__ mq, const float4* __restrict__ ray_o,
                                                   const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                   unsigned& n_int, unsigned& n_tri, unsigned& n_inst,
                                                   const DMesh* lmesh = nullptr, uint8_t* __restrict__ side_out = nullptr) {
-    constexpr unsigned WAVES = HPT_BLOCK / 64, QW = HPT_QUEUE_CAP / WAVES;
-    static_assert((QW & (QW - 1)) == 0 && QW >= 128, "per-wave ring: power of two, room for 63 + 64 items");
+    constexpr unsigned WAVES = HPT_BLOCK / 64;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     int* stk = L.stack + threadIdx.x;
-    uint2* queue = L.queue + wave * QW;
     unsigned long long* mybest = L.best + threadIdx.x;
     const unsigned lbase = wave * HPT_LEAF_CAP;
     const int SENTINEL = (int)0x80000000;
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
     PieceFeed<DYNAMIC> feed(wv);
-    unsigned qn = 0, qhead = 0, pend = 0;                // wave-uniform: ring counters (monotonic), pending-list fill
+    uint32_t piece_slot = 0, piece_n = 0, piece_pos = 0;      // wave-uniform: the piece items are being handed out from
+    bool input_done = false;
+    unsigned pend = 0;                                        // wave-uniform: pending-list fill
     bool have = false;
     uint32_t slot = 0; int mpos = 0, first_mpos = 0;
     f3 lo = mk3(0, 0, 0), ld = mk3(0, 0, 1);
@@ -525,67 +530,35 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     float bound_s = HPT_INF;      // min(nearest triangle of this mesh as of the last batch, scene-level nearest) * HPT_SLACK
     int ref = SENTINEL, sp = 1, inst_idx = 0;
     for (;;) {
-        // ---- phase 1 until a full wave of rays is queued (or the input ends)
-        while (!feed.done() && qn - qhead < 64u) {
-            uint32_t x;
-            if (!feed.next(x)) break;
-            const uint32_t w = x / WAVES, sub = x % WAVES;
-            const uint32_t seg = w % wv.shards, k = w / wv.shards;
-            const uint32_t cnt = wv.counts ? wv.counts[seg * HPT_COUNT_STRIDE] : wv.n_linear;
-            const uint32_t off0 = k * HPT_BLOCK + sub * 64u;
-            if (off0 >= cnt) continue;
-            const uint32_t i = seg * wv.cap + off0 + lane;
-            bool queued = false;
-            uint2 item = make_uint2(0, 0);
-            const bool valid = off0 + lane < cnt;
-            if constexpr (LOCAL) {
-                if (valid) {
-                    float tin;
-                    queued = box_hit(make_raybox(xyz(ray_o[i]), xyz(ray_d[i])), make_float3(lmesh->bmin[0], lmesh->bmin[1], lmesh->bmin[2]),
-                                     make_float3(lmesh->bmax[0], lmesh->bmax[1], lmesh->bmax[2]), HPT_INF, tin);
-                    item = make_uint2(i, 0u);
-                    hit[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); side_out[i] = 0;             // final unless a triangle is hit
-                }
-            } else {
-#if HPT_PHASE1_CULL
-                Hit a;
-                const f3 po = valid ? xyz(ray_o[i]) : mk3(0, 0, 0), pd = valid ? xyz(ray_d[i]) : mk3(0, 0, 1);
-                queued = analytic_phase_culled<COUNT>(sc, L, valid, po, pd, i, a, item, n_inst);      // the whole wave takes part
-                if (valid) { hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side; }   // final for unqueued rays, interim otherwise
-#else
-                if (valid) {
-                    Hit a;
-                    queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, a, item, n_inst);
-                    hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
-                }
-#endif
-            }
-            const unsigned long long mask = __ballot(queued);
-            if (queued) queue[(qn + lane_prefix(mask)) & (QW - 1u)] = item;
-            qn += (unsigned)__popcll(mask);
-            // the interim records are read back by whichever lane of this wave pulls the ray
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        }
-        // ---- lanes without a ray pull the next queued ones
+        // ---- lanes without a ray take the next items of the queue
         bool need_setup = false;
-        {
+        while (!input_done) {
             const unsigned long long idle = __ballot(!have);
-            const unsigned avail = qn - qhead;
-            if (idle != 0ull && avail != 0u) {
-                const unsigned rank = lane_prefix(idle);
-                if (!have && rank < avail) {
-                    const uint2 it = queue[(qhead + rank) & (QW - 1u)];
-                    slot = it.x; mpos = first_mpos = (int)it.y;
-                    // 8-byte items keep the rings at 4 KB of LDS; the best analytic hit of phase 1 comes back from
-                    // hit[] / hit_inst[] (L2-resident)
-                    if constexpr (!LOCAL) { ht = hit[slot].x; hinst = hit_inst[slot]; }
-                    have = true; need_setup = true;
+            if (idle == 0ull) break;
+            if (piece_pos >= piece_n) {
+                bool found = false;
+                uint32_t x;
+                while (feed.next(x)) {
+                    const uint32_t w = x / WAVES, sub = x % WAVES;
+                    const uint32_t seg = w % wv.shards, k = w / wv.shards;
+                    const uint32_t cnt = wv.counts ? wv.counts[seg * HPT_COUNT_STRIDE] : wv.n_linear;
+                    const uint32_t off0 = k * HPT_BLOCK + sub * 64u;
+                    if (off0 < cnt) { piece_slot = seg * wv.cap + off0; piece_n = min(64u, cnt - off0); piece_pos = 0; found = true; break; }
                 }
-                const unsigned nidle = (unsigned)__popcll(idle);
-                qhead += nidle < avail ? nidle : avail;
+                if (!found) { input_done = true; break; }
             }
+            const uint32_t left = piece_n - piece_pos, nidle = (uint32_t)__popcll(idle), take = nidle < left ? nidle : left;
+            const uint32_t rank = lane_prefix(idle);
+            if (!have && rank < take) {
+                const uint2 it = mq[piece_slot + piece_pos + rank];
+                slot = it.x; mpos = first_mpos = (int)it.y;
+                // the best analytic hit of the ray comes from hit[] / hit_inst[] (written by the analytic stage's launch)
+                if constexpr (!LOCAL) { ht = hit[slot].x; hinst = hit_inst[slot]; }
+                have = true; need_setup = true;
+            }
+            piece_pos += take;
         }
-        const bool exhausted = feed.done() && qn == qhead;      // nothing left to pull, ever
+        const bool exhausted = input_done;      // nothing left to pull, ever
         // ---- lanes whose mesh is finished (nothing of theirs is pending: the list was emptied below) merge its result
         //      and move on to the ray's next mesh instance
         if (LOCAL && have && !need_setup && ref == SENTINEL) {
@@ -638,7 +611,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                     ray_level(in->lv[1], lo, ld);
                     for (int k = 2; k < nlev; ++k) ray_level(sc.xinv[in->xf_first + k], lo, ld);
                 }
-                if (COUNT && mpos > first_mpos) n_inst++;   // the first one was counted by the analytic phase
+                if (COUNT && mpos > first_mpos) n_inst++;   // the first one was counted by the analytic stage
                 const DMesh* mesh = sc.meshes + in->mesh;
                 rb = make_raybox(lo, ld);
                 float tin;
@@ -675,16 +648,18 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 cl = ref;
                 --sp; ref = stk[sp * HPT_BLOCK];
             }
+            // leaf children join the pending list: left ones, then right ones, a batch tested whenever 64 are pending --
+            // at most 63 + 64 entries at any time (HPT_LEAF_CAP 128)
             const unsigned long long mL = __ballot(cl < 0), mR = __ballot(cr < 0);
             if (mL | mR) {
+                bool tested = false;
                 if (cl < 0) { const unsigned e = lbase + pend + lane_prefix(mL); L.ltri[e] = (uint32_t)~cl; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mL);
+                if (pend >= 64u) { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); tested = true; }
                 if (cr < 0) { const unsigned e = lbase + pend + lane_prefix(mR); L.ltri[e] = (uint32_t)~cr; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mR);
-                if (pend >= 64u) {
-                    do { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); } while (pend >= 64u);
-                    bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
-                }
+                if (pend >= 64u) { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); tested = true; }
+                if (tested) bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
             }
         }
         // ---- what is still pending is tested before any lane merges or changes its ray
@@ -888,15 +863,15 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
             }
             if constexpr (!DEFER) continue;
             const unsigned long long mL = __ballot(anaL), mR = __ballot(anaR);
-            if (mL | mR) {
+            if (mL | mR) {      // (a batch is tested between the two sides: at most 63 + 64 entries, HPT_LEAF_CAP 128)
+                bool tested = false;
                 if (anaL) L.ltri[lbase + pend + lane_prefix(mL)] = (lane << 26) | ((uint32_t)~l - (uint32_t)HPT_ANALYTIC_BASE);
                 pend += (unsigned)__popcll(mL);
+                if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); tested = true; }
                 if (anaR) L.ltri[lbase + pend + lane_prefix(mR)] = (lane << 26) | ((uint32_t)~r - (uint32_t)HPT_ANALYTIC_BASE);
                 pend += (unsigned)__popcll(mR);
-                if (pend >= 64u) {
-                    do { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); } while (pend >= 64u);
-                    ta = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
-                }
+                if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); tested = true; }
+                if (tested) ta = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
             }
         }
         // ---- what is still pending is tested before any lane retires its ray
@@ -916,14 +891,40 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_trace_rays
+// Mesh::intersect entry (geometry.rs:132-158) in two launches, like the extend step of a render: the root-box pass
+// (bvh.rs:149; every ray gets its "miss" record, the rays that enter the box go to the one-segment mesh queue), then the
+// persistent traversal over that queue.
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_trace_rootbox(DMesh mesh, uint32_t n, const float4* __restrict__ org, const float4* __restrict__ dir, float4* __restrict__ hit,
+                uint8_t* __restrict__ side_out, uint2* __restrict__ mq, uint32_t* __restrict__ mq_counts, uint32_t mq_cap) {
+    const unsigned lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * HPT_BLOCK; base < n; base += gridDim.x * HPT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t seg = (base / HPT_BLOCK) % HPT_SHARDS;      // chunk c appends to segment c % 64 (one counter for 10 M rays: 156 k serialised atomics = 1.7 ms)
+        bool queued = false;
+        if (i < n) {
+            float tin;
+            queued = box_hit(make_raybox(xyz(org[i]), xyz(dir[i])), make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]),
+                             make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin);
+            hit[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); side_out[i] = 0;      // final unless a triangle is hit
+        }
+        const unsigned long long mask = __ballot(queued);
+        if (mask) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&mq_counts[seg * HPT_COUNT_STRIDE], (uint32_t)__popcll(mask));
+            wbase = __shfl(wbase, 0);
+            if (queued) mq[seg * mq_cap + wbase + lane_prefix(mask)] = make_uint2(i, 0u);
+        }
+    }
+}
 template <bool COUNT, bool NODE32>
 __global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(HPT_EXTEND_WAVES, HPT_EXTEND_WAVES)))
 k_trace_rays(DScene sc, int stack_entries, DMesh mesh, uint32_t n, const float4* __restrict__ org, const float4* __restrict__ dir,
-             float4* __restrict__ hit, uint8_t* __restrict__ side_out, unsigned long long* stat) {
+             float4* __restrict__ hit, uint8_t* __restrict__ side_out, unsigned long long* stat, const uint2* __restrict__ mq, const uint32_t* __restrict__ mq_count, uint32_t mq_cap) {
     Lds L = lds_carve(stack_entries);
-    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = n; wv.cap = (n + HPT_BLOCK - 1) / HPT_BLOCK * HPT_BLOCK; wv.work = nullptr;
+    WorkView wv; wv.counts = mq_count; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.cap = mq_cap; wv.work = nullptr;
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
-    block_closest_hit<COUNT, NODE32, true>(sc, L, wv, org, dir, hit, nullptr, n_int, n_tri, n_inst, &mesh, side_out);
+    block_closest_hit<COUNT, NODE32, true>(sc, L, wv, mq, org, dir, hit, nullptr, n_int, n_tri, n_inst, &mesh, side_out);
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri);
         if ((threadIdx.x & 63) == 0) { atomicAdd(&stat[1], a); atomicAdd(&stat[2], b); }
@@ -992,11 +993,30 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     }
 #endif
     if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
-    else block_closest_hit<COUNT, NODE32, false, DYN>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    else {
+        wv.counts = ps.counts + HPT_MQ_COUNTS(depth);      // instance-list path: the input is the mesh queue k_extend_a filled
+        block_closest_hit<COUNT, NODE32, false, DYN>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    }
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
                            c = wave_sum<unsigned long long>(n_inst);
         if ((threadIdx.x & 63) == 0) { atomicAdd(&ps.stat[1], a); atomicAdd(&ps.stat[2], b); atomicAdd(&ps.stat[3], c); }
+    }
+}
+
+// the analytic stage of the instance-list path (see block_analytic): every ray of this depth's queue
+template <bool COUNT>
+__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_extend_a(DScene sc, DPass ps, int depth) {
+    const DQueue& q = ps.q[depth & 1];
+    WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.work = nullptr;
+    unsigned n_inst = 0, n_queued = 0;
+    block_analytic<COUNT>(sc, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, ps.mq, ps.counts + HPT_MQ_COUNTS(depth), HPT_SHARDS, ps.shard_cap, n_inst, n_queued);
+    const unsigned long long nq = wave_sum<unsigned long long>(n_queued);
+    if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&ps.stat[5], nq);
+    if (COUNT) {
+        const unsigned long long c = wave_sum<unsigned long long>(n_inst);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&ps.stat[3], c);
     }
 }
 
@@ -1139,17 +1159,28 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
 // ------------------------------------------------------------------------------------------------ k_scene_intersect
 // test entry for Scene::intersect: the same closest-hit code as k_extend, then the HitInfo rebuild
 __global__ void __launch_bounds__(HPT_BLOCK)
+k_scene_analytic(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
+                 float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, uint2* __restrict__ mq, uint32_t* __restrict__ mq_count, uint32_t mq_cap) {
+    WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n; wv.work = nullptr;
+    wv.cap = (uint32_t)((n + HPT_BLOCK - 1) / HPT_BLOCK) * HPT_BLOCK;
+    unsigned c0 = 0, c1 = 0;
+    block_analytic<false>(sc, wv, org, dir, hit, hit_inst, mq, mq_count, HPT_SHARDS, mq_cap, c0, c1);
+}
+// (instance-list scenes: the input is the sharded mesh queue k_scene_analytic filled)
+__global__ void __launch_bounds__(HPT_BLOCK)
 k_scene_closest(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
-                float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, int stack_entries, int defer) {
+                float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, int stack_entries, int defer,
+                const uint2* __restrict__ mq, const uint32_t* __restrict__ mq_count, uint32_t mq_cap) {
     Lds L = sc.use_tlas ? lds_carve_tlas(stack_entries, defer != 0) : lds_carve(stack_entries);
     unsigned c0 = 0, c1 = 0, c2 = 0;
     WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n; wv.work = nullptr;
     wv.cap = (uint32_t)((n + HPT_BLOCK - 1) / HPT_BLOCK) * HPT_BLOCK;
+    if (!sc.use_tlas) { wv.counts = mq_count; wv.shards = HPT_SHARDS; wv.cap = mq_cap; }
     if (sc.use_tlas) {
         if (defer) { if (sc.node32) block_closest_hit_tlas<false, true, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit_tlas<false, false, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
         else { if (sc.node32) block_closest_hit_tlas<false, true, false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit_tlas<false, false, false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
     }
-    else { if (sc.node32) block_closest_hit<false, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit<false, false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
+    else { if (sc.node32) block_closest_hit<false, true>(sc, L, wv, mq, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit<false, false>(sc, L, wv, mq, org, dir, hit, hit_inst, c0, c1, c2); }
 }
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_scene_hitinfo(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
@@ -1436,7 +1467,7 @@ static inline int carve_entries(int stack_entries, bool tlas) { return tlas ? st
 enum { LDS_STACK = 0, LDS_LIST = 1, LDS_TLAS = 2 };
 static inline size_t trav_lds_bytes(int stack_entries, int mode) {
     size_t n = (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16;
-    if (mode == LDS_LIST) n += HPT_QUEUE_CAP * sizeof(uint2) + (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 + (HPT_LDS_TOPCACHE ? 16 + (size_t)HPT_LDS_TOPCACHE * 64 : 0);
+    if (mode == LDS_LIST) n += (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 + (HPT_LDS_TOPCACHE ? 16 + (size_t)HPT_LDS_TOPCACHE * 64 : 0);
     if (mode == LDS_TLAS) n += (size_t)HPT_BLOCK * 8 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 4;
     return n;
 }
@@ -1472,9 +1503,15 @@ static int scene_lds_mode(int stack_entries, const DScene& sc) {
     const int with = extend_resident(sc, true, trav_lds_bytes(stack_entries, LDS_TLAS)), without = extend_resident(sc, false, trav_lds_bytes(stack_entries, LDS_STACK));
     return (with > 0 && with >= without) ? LDS_TLAS : LDS_STACK;
 }
+// slots of a mesh queue sharded HPT_SHARDS ways for n rays in 256-ray chunks (chunk c appends to segment c % HPT_SHARDS)
+size_t hptk_mq_slots(uint64_t n) {
+    const uint64_t chunks = (n + HPT_BLOCK - 1) / HPT_BLOCK;
+    return (size_t)(((chunks + HPT_SHARDS - 1) / HPT_SHARDS) * HPT_BLOCK * HPT_SHARDS);
+}
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
-                     const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat) {
-    // the same persistent closest-hit machinery as k_extend, fed with mesh-local rays (slots are 32-bit: 2^30 rays per launch)
+                     const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat, uint2* mq, uint32_t* mq_count) {
+    // the same persistent closest-hit machinery as k_extend, fed with mesh-local rays (slots are 32-bit: 2^30 rays per launch);
+    // mq: hptk_mq_slots(min(n, 2^30)) items; mq_count: HPT_COUNTS_PER_DEPTH counters per 2^30-ray launch, zeroed by the caller
     const int se = carve_entries(mesh.stack_need, false);
     const size_t lds = trav_lds_bytes(se, LDS_LIST);
     auto k = sc.node32 ? (count ? k_trace_rays<true, true> : k_trace_rays<false, true>) : (count ? k_trace_rays<true, false> : k_trace_rays<false, false>);
@@ -1482,19 +1519,28 @@ void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMe
     if (per_cu <= 0) per_cu = 4;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = max_blocks / 4;
-    for (long long base = 0; base < n; base += (1ll << 30)) {
+    int launch = 0;
+    for (long long base = 0; base < n; base += (1ll << 30), ++launch) {
         const uint32_t m = (uint32_t)std::min<long long>(n - base, 1ll << 30);
+        const uint32_t cap = (uint32_t)(hptk_mq_slots(m) / HPT_SHARDS);
+        uint32_t* counts = mq_count + (size_t)launch * HPT_COUNTS_PER_DEPTH;
+        hipLaunchKernelGGL(k_trace_rootbox, dim3(grid_for(m, max_blocks)), dim3(HPT_BLOCK), 0, st, mesh, m, org + base, dir + base, hit + base, side + base, mq, counts, cap);
         const int grid = grid_for(m, std::max(1, cus * per_cu));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(HPT_BLOCK), lds, st, sc, se, mesh, m, org + base, dir + base, hit + base, side + base, stat);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(HPT_BLOCK), lds, st, sc, se, mesh, m, org + base, dir + base, hit + base, side + base, stat, (const uint2*)mq, (const uint32_t*)counts, cap);
     }
 }
 void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
-                          float4* pos, float4* normal, float4* uvw) {
+                          float4* pos, float4* normal, float4* uvw, uint2* mq, uint32_t* mq_count) {
     const int grid = grid_for((uint64_t)n, max_blocks);
     stack_entries = carve_entries(stack_entries, sc.use_tlas != 0);
     const int mode = scene_lds_mode(stack_entries, sc);
-    hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries, mode), st, sc, n, org, dir, hit, hit_inst, stack_entries, mode == LDS_TLAS ? 1 : 0);
+    if (!sc.use_tlas) {      // analytic stage first: hit records of every ray + the mesh queue (mq_count zeroed by the caller)
+        hipLaunchKernelGGL(k_scene_analytic, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, mq, mq_count, (uint32_t)(hptk_mq_slots((uint64_t)n) / HPT_SHARDS));
+    }
+    if (sc.use_tlas || sc.n_mesh_instances > 0)
+    hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries, mode), st, sc, n, org, dir, hit, hit_inst, stack_entries, mode == LDS_TLAS ? 1 : 0,
+                       (const uint2*)mq, (const uint32_t*)mq_count, (uint32_t)(hptk_mq_slots((uint64_t)n) / HPT_SHARDS));
     hipLaunchKernelGGL(k_scene_hitinfo, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, node, prim, t, side, pos, normal, uvw);
 }
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
@@ -1509,6 +1555,7 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     p.extend_mode = scene_lds_mode(p.extend_entries, sc);
     p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode);
     p.extend_per_cu = extend_resident(sc, p.extend_mode == LDS_TLAS, p.extend_lds);
+    p.analytic_per_cu = resident_blocks(k_extend_a<false>, 0);
     p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
     p.shade_lds = p.shade_tables <= 24 * 1024;
     // resident workgroups of k_shade per CU (0: query failed); the pass launches a multiple of it -- work is strided
@@ -1518,6 +1565,10 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
 }
 static int g_refill = 24;
 void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }
+void hptk_extend_analytic(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, bool count) {
+    if (count) hipLaunchKernelGGL(k_extend_a<true>, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth);
+    else hipLaunchKernelGGL(k_extend_a<false>, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth);
+}
 void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, bool count) {
     // one kernel per (instrumented, two-level, node format, deferral) combination: each path gets its own register allocation
     auto k = count ? extend_kernel<true>(sc, plan.extend_mode == LDS_TLAS) : extend_kernel<false>(sc, plan.extend_mode == LDS_TLAS);
@@ -1561,7 +1612,7 @@ void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint3
 // ------------------------------------------------------------------------------------------------ static workspace
 // The pass buffers of hpt_render_device_noalloc (include/hpt.h): wavefront queues, hit records, radiance records, append
 // counters, statistics, Halton table for a frame of up to HPT_NOALLOC_MAX_PATHS pixels -- HPT_NOALLOC_SCRATCH_BYTES
-// (71.9 MB) of device memory that every GPU the library runs on holds from the first load of this code object to the end
+// (76.8 MB) of device memory that every GPU the library runs on holds from the first load of this code object to the end
 // of the process.  The array's NAME is a host-side stand-in, not a device address: host code gets each device's copy
 // through hipGetSymbolAddress (once per device, with that device current) and uses that pointer -- for kernel arguments,
 // hipMemsetAsync and copies alike.  The kernels take the pointer as an argument, exactly as they take the hipMalloc'ed

@@ -3,18 +3,22 @@
 #include <hip/hip_runtime.h>
 #include "hpt_device.h"
 
+size_t hptk_mq_slots(uint64_t n);      // items a sharded mesh queue for n rays holds (test entries; a pass uses its queue geometry)
 void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMesh& mesh, long long n, const float4* org,
-                     const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat);
+                     const float4* dir, float4* hit, uint8_t* side, bool count, unsigned long long* stat, uint2* mq, uint32_t* mq_count);
 void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
-                          float4* pos, float4* normal, float4* uvw);
+                          float4* pos, float4* normal, float4* uvw, uint2* mq, uint32_t* mq_count);
 void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps);
 struct HptkPlan {          // what hptk_plan derives from a committed scene (see hpt_kernels.hip)
     int extend_entries = 1, extend_mode = 0, extend_per_cu = 0;   // stack entries carved, LDS layout, resident workgroups per CU (0: query failed)
     size_t extend_lds = 0;
+    int analytic_per_cu = 0;                                      // resident workgroups per CU of k_extend_a
     size_t shade_tables = 0; bool shade_lds = false; int shade_per_cu = 0;
 };
 void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPlan* out);
+// instance-list scenes: analytic stage of a depth (every ray; fills the mesh queue), then hptk_extend over the mesh queue
+void hptk_extend_analytic(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, bool count);
 void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, bool count);
 void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat);
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax);

@@ -50,7 +50,8 @@ class RenderStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("inst_tests", C.c_uint64), ("seconds_total", C.c_double),
                 ("seconds_raygen", C.c_double), ("seconds_extend", C.c_double), ("seconds_shade", C.c_double),
-                ("seconds_resolve", C.c_double), ("launches_extend", C.c_uint32), ("passes", C.c_uint32), ("samples", C.c_uint64)]
+                ("seconds_resolve", C.c_double), ("launches_extend", C.c_uint32), ("passes", C.c_uint32), ("samples", C.c_uint64),
+                ("seconds_analytic", C.c_double), ("rays_mesh", C.c_uint64)]
 
 
 class TraceStats(C.Structure):

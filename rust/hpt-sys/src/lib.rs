@@ -61,6 +61,7 @@ pub struct hpt_render_stats {
     pub seconds_raygen: f64, pub seconds_extend: f64, pub seconds_shade: f64, pub seconds_resolve: f64,
     pub launches_extend: u32, pub passes: u32,
     pub samples: u64,
+    pub seconds_analytic: f64, pub rays_mesh: u64,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
@@ -123,7 +124,7 @@ extern "C" {
                       stats: *mut hpt_render_stats) -> c_int;
     pub fn hpt_render_device(scene: *mut hpt_scene, params: *const hpt_render_params, rgb_sum_device: *mut f32,
                              stats: *mut hpt_render_stats) -> c_int;
-    /// `hpt_render_device` for callers that cannot allocate: pass buffers from a static 72 MB device array, at most 2^19
+    /// `hpt_render_device` for callers that cannot allocate: pass buffers from a static 77 MB device array, at most 2^19
     /// pixels and 4096 samples per call; calls that overlap on one GPU race.
     pub fn hpt_render_device_noalloc(scene: *mut hpt_scene, params: *const hpt_render_params, rgb_sum_device: *mut f32,
                                      stats: *mut hpt_render_stats) -> c_int;

@@ -17,8 +17,8 @@ def run(name, desc, tree=True, spp=16, S=4, depth=8, bpc=None):
     cst = sc.render_device(out.data_ptr(), want_stats=True, spp=cspp, max_depth=depth, seed=1, spp_per_pass=max(S, cspp), flags=hpt.RENDER_COUNTERS)
     st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_TIME_KERNELS)
     rays = st.rays_primary + st.rays_bounce; cr = cst.rays_primary + cst.rays_bounce
-    print("%-28s total %.3fs %7.1f Mrays/s | extend %.4f (%.2f Grays/s) shade %.4f | nodes/ray %.2f tris/ray %.2f inst/ray %.1f" % (
-        name, st.seconds_total, rays / st.seconds_total / 1e6, st.seconds_extend, rays / st.seconds_extend / 1e9, st.seconds_shade,
+    print("%-28s total %.3fs %7.1f Mrays/s | analytic %.4f extend %.4f (%.2f Grays/s) shade %.4f | nodes/ray %.2f tris/ray %.2f inst/ray %.1f" % (
+        name, st.seconds_total, rays / st.seconds_total / 1e6, st.seconds_analytic, st.seconds_extend, rays / max(st.seconds_extend + st.seconds_analytic, 1e-9) / 1e9, st.seconds_shade,
         cst.nodes_visited / cr, cst.tris_tested / cr, cst.inst_tests / cr), flush=True)
     sc.close()
 
@@ -43,6 +43,11 @@ def main():
                     hpt.lib.hpt_debug_set_refill(r)
                     run("refill %d (rep %d)" % (r, rep), d)
             hpt.lib.hpt_debug_set_refill(24)
+        elif w.startswith("NTB"):      # phase 1 alone (no mesh) at several occupancies
+            d.nodes = [n for n in d.nodes if n.geom != 3]; d.meshes = []
+            for b in [int(c) for c in w[3:].split(",")]:
+                run("no teapot, blocks/CU %d" % b, d, bpc=b)
+            hpt.lib.hpt_debug_set_extend_blocks(run.ctx.h, 0)
         elif w.startswith("B"):
             for b in [int(c) for c in w[1:].split(",")]:
                 run("blocks/CU %d" % b, d, bpc=b)

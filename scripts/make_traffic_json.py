@@ -21,7 +21,7 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- py
        "unit": "KB per launch as rocprofv3 reports; bytes = KB*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B reads at 64 B)",
        "rays_per_launch": b["rays_per_step"] / b["roofline"]["launches"],
        "source_sha256": source_sha256(), "source_files": list(STAMPED)}
-for key, name in (("k_extend", "void k_extend<false, false"), ("k_shade", "void k_shade<true>")):
+for key, name in (("k_extend", "void k_extend<false, false"), ("k_extend_a", "void k_extend_a<false>"), ("k_shade", "void k_shade<true>")):
     f, n = grab(src + "/pmc_fetch_summary.txt", name, "FETCH_SIZE")
     w, _ = grab(src + "/pmc_write_summary.txt", name, "WRITE_SIZE")
     out[key] = {"launches": n, "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes_per_launch": int((2 * f + w) * 1024)}

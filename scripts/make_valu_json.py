@@ -27,7 +27,7 @@ what = sys.argv[3] if len(sys.argv) > 3 else "8 (1080p teapot, passes of 4 spp =
 res = {"command": "rocprofv3 --pmc <8 SQ counters> -- python3 scripts/gpu_prof.py " + what,
        "source_sha256": source_sha256(), "source_files": list(STAMPED),
        "formula": "valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32 shader engines)"}
-for key, name in (("k_extend", "void k_extend<false, false"), ("k_shade", "void k_shade<true>")):
+for key, name in (("k_extend", "void k_extend<false, false"), ("k_extend_a", "void k_extend_a<false>"), ("k_shade", "void k_shade<true>")):
     b = block(name)
     cycles = b["SQ_BUSY_CYCLES"] / SES
     res[key] = {"launches": b["launches"], "valu_wave_insts_per_launch": b["SQ_INSTS_VALU"], "salu_wave_insts_per_launch": b["SQ_INSTS_SALU"],
