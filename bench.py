@@ -316,7 +316,9 @@ def main():
                             "source": traffic["source"], "stale": traffic["stale"]}
         limiter = None
         if valu and hbm_physical:
-            limiter = "valu_issue" if valu["frac"] >= hbm_physical["frac"] else "hbm"
+            # what the counters say: a pipe that is busy most of the time limits the kernel; when neither the vector ALUs nor
+            # the HBM pins are, the waves are waiting on dependent fetches (node -> child node through L2)
+            limiter = "valu_issue" if valu["frac"] >= 0.7 and valu["frac"] >= hbm_physical["frac"] else ("hbm" if hbm_physical["frac"] >= 0.6 else "latency")
         if args.config == "teapot":
             bvh_text = ("reference bvh.rs tree built on host; library restructures it at flatten time (SAH re-partition + insertion rounds), tight refit"
                         if info.trees_optimized else "reference bvh.rs tree built on host, tight refit") if args.tree == "host" else "library SAH"

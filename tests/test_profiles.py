@@ -48,7 +48,7 @@ def test_bench_lines_in_profiles_carry_the_contract_fields():
     if "hbm_physical" in r:      # round 2 on: the physical side beside the nominal (algorithmic) figure
         h = r["hbm_physical"]
         assert h is None or (abs(h["frac"] - h["GB/s"] / r["peak"]) < 1e-3 and h["bytes_per_launch"] == r["traffic"])
-        assert r["limiter"] in (None, "hbm", "valu_issue")
+        assert r["limiter"] in (None, "hbm", "valu_issue", "latency")
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert "workload" in line["config"] and "model" not in line["config"]
