@@ -1,0 +1,81 @@
+"""The C oracle (oracle/oracle.c) held to a second restatement of the same .rs text (tests/restatement2.py: numpy f32,
+brute-force Mesh::intersect, recursive Node::intersect with per-call Matrix3::invert, Scene::cast as a fold).  Neither
+is pinned to the Rust binary (nothing reference-held exists) -- two independent readings that agree halve the
+single-reader risk ("hard parts")."""
+import numpy as np
+
+import rays as R
+import restatement2 as r2
+from conftest import resized
+
+
+def test_mesh_intersect_4096_rays(oscene, desc):
+    mesh = desc.meshes[0]
+    org, dirs = R.parity_rays(oscene.meshes[0].box(), 4096)
+    o = oscene.meshes[0].intersect(org, dirs)
+    pre = r2.box_intersect(mesh.verts.min(axis=0), mesh.verts.max(axis=0), org, dirs)        # geometry.rs:31
+    prim, t, u, v, front = r2.mesh_intersect(mesh, org, dirs)
+    prim = np.where(pre, prim, -1)
+    same = prim == o["prim"]
+    # the oracle visits candidates in BVH order, the brute force in index order: exact-t ties (shared edges) may name
+    # another triangle -- only there
+    bad = ~same
+    assert bad.sum() <= 8
+    if bad.any():
+        assert ((prim[bad] >= 0) & (o["prim"][bad] >= 0)).all()
+        np.testing.assert_array_equal(t[bad], o["t"][bad])
+        assert (np.minimum(R.edge_distance(o["u"][bad], o["v"][bad]), R.edge_distance(u[bad], v[bad])) < 1e-6).all()
+    both = same & (prim >= 0)
+    assert both.sum() > 1000
+    for mine, key in ((t, "t"), (u, "u"), (v, "v"), (front.astype(np.uint8), "side")):
+        np.testing.assert_array_equal(mine[both], o[key][both])
+
+
+def _scene_rays(oscene, desc, n, seed):
+    rng = np.random.default_rng(seed)
+    cam = desc.camera
+    pr = [oscene.primary_ray(int(x), int(y), 1 + int(k), 1) for x, y, k in zip(rng.integers(0, cam.width, n // 2), rng.integers(0, cam.height, n // 2), rng.integers(0, 8, n // 2))]
+    o = np.array([p[0] for p in pr], np.float32); d = np.array([p[1] for p in pr], np.float32)
+    h = oscene.intersect(o, d)
+    ok = h["node"] >= 0
+    o2 = (h["pos"][ok] + 0.01 * h["normal"][ok]).astype(np.float32)
+    d2 = rng.normal(size=o2.shape); d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+    return np.concatenate([o, o2]), np.concatenate([d, d2])
+
+
+def test_scene_intersect_2048_rays(oscene, desc):
+    o, d = _scene_rays(oscene, desc, 2048, 11)
+    ref = oscene.intersect(o, d)
+    h = r2.scene_intersect(desc, o, d)
+    node = np.where(np.isfinite(h.t), h.node, -1)
+    same = node == ref["node"]
+    assert same.mean() > 0.999, same.mean()
+    hit = same & (node >= 0)
+    np.testing.assert_array_equal(h.t[hit], ref["t"][hit])
+    np.testing.assert_array_equal(h.front[hit].astype(np.uint8), ref["side"][hit])
+    prim_same = hit & (np.where(h.prim >= 0, h.prim, -1) == ref["prim"])
+    assert prim_same.sum() >= hit.sum() - 2
+    np.testing.assert_array_equal(h.pos[prim_same], ref["pos"][prim_same])
+    np.testing.assert_array_equal(h.normal[prim_same], ref["normal"][prim_same])
+    # uv: atan2 / asin of the sphere come from numpy here and from libm there (<= 2 ulp)
+    np.testing.assert_allclose(h.uv[prim_same], ref["uvw"][prim_same], rtol=0, atol=3e-7)
+    kinds = {desc.nodes[k].geom for k in node[hit]}
+    assert kinds == {1, 2, 3}                    # sphere, planes and the mesh all take part
+
+
+def test_primary_rays_and_radiance_64x48_1spp(oscene, olib, desc):
+    import oracle_lib as ol
+    d = resized(desc, 64, 48)
+    osc = ol.OracleScene(olib, d)
+    eye, dirs, _ = r2.primary_rays(d.camera, np.arange(64 * 48, dtype=np.uint32), 3, 1)
+    for pix in (0, 63, 64 * 20 + 31, 64 * 48 - 1):
+        o, dd = osc.primary_ray(pix % 64, pix // 64, 3, 1)
+        np.testing.assert_array_equal(eye[pix], o); np.testing.assert_array_equal(dirs[pix], dd)
+    ref = osc.render(spp=1, max_depth=8, seed=1, want_samples=True)["per_sample"][:, 0]
+    mine = r2.radiance_1spp(d, 1, 1, 8)
+    # sin / cos / asin come from numpy here and from libm in the oracle: last-bit differences, and the rare path where one
+    # of them flips a discrete choice further down
+    close = np.abs(mine - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)
+    assert close.all(axis=1).mean() >= 0.995, close.all(axis=1).mean()
+    assert ref.sum() > 0 and (ref.max(axis=1) > 0).mean() > 0.05      # (1 spp: a path has to find the light)
+    np.testing.assert_allclose(mine.mean(axis=0), ref.mean(axis=0), rtol=2e-2)
