@@ -1,0 +1,99 @@
+"""BASELINE.json configs 3-5 at FULL scene size: 1 M-triangle soup, 3 375 teapot instances (21.3 M triangles)
+under a TLAS, 10 000 spheres.  The oracle walks these scenes the reference's way (bvh.rs tree that degenerates on unordered
+input: 204 k node pops per soup ray; Scene::intersect linear in the instances), so the ray count against it is bounded
+(2-5 k rays for soup and lattice, 100 k for the spheres: each under a minute of oracle time on the box's 16 cores); the
+full-size frames are covered by size-independent properties: linearity in the environment colour, additivity over
+sample ranges, ray accounting, one-stream == two passes in flight."""
+import copy
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scenes
+from conftest import host_tree
+from test_gpu_configs import camera_and_random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def hits_against_oracle(gsc, osc, desc, n_rays, seed):
+    o, d = camera_and_random_rays(osc, desc, n_rays, seed)
+    g = gsc.intersect(o, d); r = osc.intersect(o, d)
+    same_node = g["node"] == r["node"]
+    assert same_node.mean() > 0.9995, same_node.mean()
+    assert (r["node"] >= 0).mean() > 0.2
+    np.testing.assert_array_equal(g["t"][same_node], r["t"][same_node])
+    np.testing.assert_array_equal(g["side"][same_node], r["side"][same_node])
+    same_prim = same_node & (g["prim"] == r["prim"])      # inside a mesh exact-t ties (shared edges) depend on the tree
+    assert same_prim.sum() >= same_node.sum() - max(3, len(o) // 5000)
+    np.testing.assert_array_equal(g["pos"][same_prim], r["pos"][same_prim])
+    np.testing.assert_array_equal(g["normal"][same_prim], r["normal"][same_prim])
+    return len(o)
+
+
+def frame_properties(ctx, desc, spp, depth):
+    """on the full-size frame: doubling the environment and background colours doubles the image exactly; sample ranges
+    add up bit for bit; ray totals are equal between the runs; one stream == two passes in flight"""
+    import torch
+    import hpt
+    d2 = copy.deepcopy(desc)
+    d2.environment.color = (d2.environment.color * np.float32(2.0)).astype(np.float32)
+    d2.background.color = (d2.background.color * np.float32(2.0)).astype(np.float32)
+    tree = host_tree if any(len(m.tris) < 100000 for m in desc.meshes) else None
+    sc, sc2 = hpt.Scene(ctx, desc, host_bvh=tree), hpt.Scene(ctx, d2, host_bvh=tree)
+    npix = desc.camera.width * desc.camera.height
+    a = torch.zeros(npix * 3, device="cuda"); b = torch.zeros(npix * 3, device="cuda"); c = torch.zeros(npix * 3, device="cuda")
+    torch.cuda.synchronize()
+    try:
+        st_a = sc.render_device(a.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=2)
+        st_b = sc2.render_device(b.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=2)
+        assert st_a.rays_primary == npix * spp and st_a.rays_bounce <= st_a.rays_primary * depth
+        assert (st_a.rays_primary, st_a.rays_bounce) == (st_b.rays_primary, st_b.rays_bounce)
+        assert torch.equal(a * 2.0, b) and float(a.sum()) > 0
+        k = max(1, spp // 2)
+        sc.render_round_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=k, first_sample=0, max_depth=depth, seed=2)
+        if spp > k:
+            sc.render_round_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=spp - k, first_sample=k, max_depth=depth, seed=2)
+        assert torch.equal(a, c)
+        ctx.set_passes_in_flight(1)
+        st_c = sc.render_device(c.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=2)
+        assert torch.equal(a, c) and st_c.rays_bounce == st_a.rays_bounce
+        return sc.info()
+    finally:
+        ctx.set_passes_in_flight(2)
+        sc.close(); sc2.close()
+
+
+def test_config3_soup_1m_triangles(ctx, olib):
+    import hpt
+    desc = scenes.soup(1_000_000, w=1920, h=1080)
+    gsc = hpt.Scene(ctx, desc)                               # bvh.rs degenerates on unordered input: the library builds the tree
+    info = gsc.info()
+    assert info.n_triangles == 1_000_000 and info.n_nodes == 999_999 and info.node_bytes == 32 and info.uses_tlas == 0
+    n = hits_against_oracle(gsc, ol.OracleScene(olib, desc), desc, 3000, 5)      # 1 500 camera rays + the bounce rays of their hits
+    assert n > 2000
+    gsc.close()
+    frame_properties(ctx, desc, spp=4, depth=8)
+
+
+def test_config4_3375_instanced_teapots(ctx, olib, desc):
+    import hpt
+    d = scenes.instanced(desc.meshes[0], 15, w=3840, h=2160)
+    gsc = hpt.Scene(ctx, d, host_bvh=host_tree)              # the BLAS is the handed-over bvh.rs tree, restructured at commit
+    info = gsc.info()
+    assert info.n_instances == 3376 and info.n_mesh_instances == 3375 and info.uses_tlas == 1 and info.trees_optimized == 1
+    hits_against_oracle(gsc, ol.OracleScene(olib, d), d, 4000, 6)
+    gsc.close()
+    frame_properties(ctx, d, spp=2, depth=8)
+
+
+def test_config5_10k_spheres(ctx, olib):
+    import hpt
+    d = scenes.spheres(10_000, w=1920, h=1080)
+    gsc = hpt.Scene(ctx, d)
+    info = gsc.info()
+    assert info.n_instances == 10_001 and info.uses_tlas == 1 and info.n_mesh_instances == 0
+    hits_against_oracle(gsc, ol.OracleScene(olib, d), d, 100_000, 7)
+    gsc.close()
+    frame_properties(ctx, d, spp=4, depth=16)
