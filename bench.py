@@ -315,6 +315,8 @@ def main():
                             "frac": round(phys_bytes / avg_launch_s / HBM_PEAK, 4), "bytes_per_ray": round(phys_bytes / rays_per_launch, 1),
                             "source": traffic["source"], "stale": traffic["stale"]}
         limiter = None
+        if hbm_physical and not valu:
+            limiter = "hbm" if hbm_physical["frac"] >= 0.6 else None
         if valu and hbm_physical:
             # what the counters say: a pipe that is busy most of the time limits the kernel; when neither the vector ALUs nor
             # the HBM pins are, the waves are waiting on dependent fetches (node -> child node through L2)
