@@ -67,7 +67,8 @@ struct hpt_context {
     hipStream_t aux_stream[HPT_MAX_INFLIGHT - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_done[HPT_MAX_INFLIGHT] = {};
     int overlap = 2;            // passes in flight (1 = one stream)
-    int extend_spare = 2;       // k_extend workgroup slots per CU left to the other pass when two are in flight (6 resident -> a grid of 4 per CU)
+    int extend_spare = -1;      // k_extend workgroup slots per CU left to the other pass when two are in flight; -1: whatever leaves a grid of 4 per CU
+                                // (6 resident: spare 0 / 1 / 2 / 3 = 13.42 / 13.41 / 14.05 / 13.59 Grays/s; 7 resident: 1 / 2 / 3 = 14.13 / 14.05 / 14.41)
     int num_cus = 256;
     int max_blocks = 2048;
     int extend_blocks = 1024;   // persistent grid of the test-entry traversal kernels
@@ -618,13 +619,15 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         pool.insert(pool.end(), s->images[i].px.begin(), s->images[i].px.end());
         while (pool.size() % 16) pool.push_back(0);
     }
-    // ---- node format.  Node32 (16-bit child boxes, 2 quads per node) halves the bytes of every traversal step at the
-    // price of 12 conversions.  Measured on MI355X: trees that live in L2 are bound by instruction issue and gain
-    // nothing (teapot +-1 %), trees that miss L2 gain (1 M-triangle soup, 64 MB of Node64: +7 %).  So: Node32 when the
-    // Node64 array would exceed half of the 32 MB aggregate L2 and every tree's grid resolves its leaves (outward
+    // ---- node format.  Node32 (16-bit child boxes, 2 quads per node) halves the bytes AND the load instructions of every
+    // traversal step (two dwordx4 per lane instead of four) at the price of 12 conversions (v_cvt_f32_u32 with a word
+    // select).  Round 1 measured +-1 % on the L2-resident teapot, whose traversal kernel was bound by instruction issue
+    // then; since round 2 that kernel is bound by its dependent fetches and the vector-memory front end, and Node32 wins on
+    // every workload (r02g: teapot +3 %, 3 375 instanced teapots +4.7 %, 10 k spheres +4.3 %, 1 M-triangle soup +31 %; node
+    // visits per ray unchanged to the third digit).  So: Node32 whenever every tree's grid resolves its leaves (outward
     // rounding grows a box by <= 4 quanta per axis), else Node64.  HPT_NODE_FORMAT=64 / 32 forces one.  Results do
     // not depend on it: boxes only grow, hits are decided by the exact triangle / sphere / plane tests.
-    bool node32 = nodes.size() * sizeof(float) > (16u << 20);
+    bool node32 = true;
     for (const TreeSlice& t : trees) if (t.n_interior > 0 && t.qf.quantum * 64.0 > t.qf.mean_leaf_extent) node32 = false;
     if (const char* e = getenv("HPT_NODE_FORMAT")) { if (atoi(e) == 64) node32 = false; else if (atoi(e) == 32) node32 = true; }
     std::vector<uint32_t> nodes32;
@@ -852,7 +855,8 @@ static int extend_grid(const hpt_scene* s, int inflight) {
         if (per_cu <= 0)      // query failed: register budget of the kernels (hpt_kernels.hip) and LDS fit
             per_cu = std::min(4, (int)((160u * 1024u) / std::max<size_t>(s->plan.extend_lds, 1)));
         // (instance-list kernel only; the two-level kernel: 10 k spheres +1 %, instanced teapots -2.5 %)
-        if (inflight > 1 && !s->ds.use_tlas && per_cu > ctx->extend_spare) per_cu -= ctx->extend_spare;
+        const int spare = ctx->extend_spare >= 0 ? ctx->extend_spare : std::max(per_cu - 4, 0);
+        if (inflight > 1 && !s->ds.use_tlas && per_cu > spare) per_cu -= spare;
     }
     return ctx->num_cus * std::max(1, per_cu);
 }
@@ -869,7 +873,11 @@ static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool c
     const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
     const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
     const int sblocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)s->shade_grid);
-    const int ablocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)s->analytic_grid);
+    // k_extend_a: at least 32 chunks per workgroup before the grid grows beyond 4 per CU -- a workgroup that finds nothing
+    // to do still costs its launch and its look at the 64 segment counters, and at the deep depths of a small pass most
+    // of a big grid does (8 M-path passes, 16 spp: 9.1 ms with 16 per CU, 6.9 ms with 4)
+    const uint64_t chunks = (n_paths + HPT_BLOCK - 1) / HPT_BLOCK;
+    const int ablocks = (int)std::min<uint64_t>(std::min<uint64_t>(chunks, std::max<uint64_t>(chunks / 32, (uint64_t)ctx->num_cus * 4)), (uint64_t)s->analytic_grid);
     for (int depth = 0; depth <= ps.max_depth; ++depth) {
         if (!s->ds.use_tlas) {      // instance-list path: analytic stage over every ray, then the traversal over the rays that entered a mesh box
             CHK(ev.begin(4, st)); hptk_extend_analytic(st, ablocks, s->ds, ps, depth, counters); CHK(ev.end(st));

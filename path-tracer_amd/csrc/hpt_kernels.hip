@@ -25,6 +25,7 @@
 #define HPT_EXTEND_WAVES 6       // mesh-queue traversal kernel: 71 VGPRs, 6 workgroups per CU by its 25.5 KB of LDS (18 stack entries); the two-level kernel (101..118 VGPRs) stays at 4
 #endif
 #ifndef HPT_SHADE_WAVES
+#define HPT_EXTEND16_WAVES 7     // the same kernel with 16-bit stack entries (scenes below 65 536 nodes): 16.5 KB of LDS, 7 workgroups per CU by its registers
 #define HPT_SHADE_WAVES 7
 #endif
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
@@ -249,8 +250,12 @@ template <bool NODE32>
 __device__ __forceinline__ void test_children(const float4* __restrict__ nodes, int ref, const Slab& ns, float bound_s,
                                               bool& hitL, bool& hitR, float& tinL, float& tinR, int& l, int& r, const float4* top = nullptr) {
     if constexpr (NODE32) {
-        const uint4* nq = (const uint4*)nodes + (uint32_t)ref * 2u;
-        const uint4 q0 = nq[0], q1 = nq[1];
+        uint4 q0, q1;
+#if HPT_LDS_TOPCACHE
+        if (top && ref < HPT_LDS_TOPCACHE) { const uint4* lq = (const uint4*)top + ref * 2; q0 = lq[0]; q1 = lq[1]; }
+        else
+#endif
+        { const uint4* nq = (const uint4*)nodes + (uint32_t)ref * 2u; q0 = nq[0]; q1 = nq[1]; }
         hitL = qbox_hit(ns, q0.x, q0.y, q0.z, bound_s, tinL);
         hitR = qbox_hit(ns, q1.x, q1.y, q1.z, bound_s, tinR);
         l = (int)q0.w; r = (int)q1.w;
@@ -288,12 +293,12 @@ struct Lds {
 };
 #define HPT_KEY_NONE 0x7f800000ffffffffull      // key of "no hit": t = +inf, no triangle / instance
 #define HPT_LEAF_CAP 128      // >= 63 left over + 64 appended (one child side of a step; a batch is tested between the two sides)
-__device__ __forceinline__ Lds lds_carve(int stack_entries) {
+__device__ __forceinline__ Lds lds_carve(int stack_entries, bool stk16 = false) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L;
     L.stack = (int*)lds_raw;
     L.queue = nullptr;
-    L.best = (unsigned long long*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16);
+    L.best = (unsigned long long*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * (stk16 ? sizeof(uint16_t) : sizeof(int)) + 16);
     L.du = (float*)(L.best + HPT_BLOCK);
     L.dv = L.du + HPT_BLOCK;
     L.dsf = (uint32_t*)(L.dv + HPT_BLOCK);
@@ -505,14 +510,29 @@ __device__ __forceinline__ void test_pending(const Lds& L, const float4* __restr
 // (Round 1 ran the analytic stage inside this kernel, feeding a per-wave LDS ring; as a launch of its own it runs at 8
 //  waves per SIMD instead of 5 -- it was latency-bound here -- and this kernel shed 23 registers and 5.3 KB of LDS: 6
 //  workgroups per CU instead of 5.)
-template <bool COUNT, bool NODE32, bool LOCAL = false, bool DYNAMIC = false>
+// STK16: stack entries are 16 bits wide (only interior refs and the sentinel are ever pushed; the launcher asks for it when
+// every interior ref of the scene is below 0xffff): half the LDS of the stack, hence more resident workgroups.
+template <bool STK16> struct TravStack;
+template <> struct TravStack<false> {
+    int* p;
+    __device__ __forceinline__ TravStack(const Lds& L) : p(L.stack + threadIdx.x) {}
+    __device__ __forceinline__ void put(int sp, int ref) { p[sp * HPT_BLOCK] = ref; }
+    __device__ __forceinline__ int get(int sp) const { return p[sp * HPT_BLOCK]; }
+};
+template <> struct TravStack<true> {
+    uint16_t* p;
+    __device__ __forceinline__ TravStack(const Lds& L) : p((uint16_t*)L.stack + threadIdx.x) {}
+    __device__ __forceinline__ void put(int sp, int ref) { p[sp * HPT_BLOCK] = (uint16_t)ref; }      // the sentinel 0x80000000 is stored as 0... see get
+    __device__ __forceinline__ int get(int sp) const { const int v = (int)p[sp * HPT_BLOCK]; return sp == 0 ? (int)0x80000000 : v; }   // entry 0 is always the sentinel
+};
+template <bool COUNT, bool NODE32, bool LOCAL = false, bool DYNAMIC = false, bool STK16 = false>
 __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const uint2* __restrict__ mq, const float4* __restrict__ ray_o,
                                                   const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                   unsigned& n_int, unsigned& n_tri, unsigned& n_inst,
                                                   const DMesh* lmesh = nullptr, uint8_t* __restrict__ side_out = nullptr) {
     constexpr unsigned WAVES = HPT_BLOCK / 64;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    int* stk = L.stack + threadIdx.x;
+    TravStack<STK16> stk(L);
     unsigned long long* mybest = L.best + threadIdx.x;
     const unsigned lbase = wave * HPT_LEAF_CAP;
     const int SENTINEL = (int)0x80000000;
@@ -596,7 +616,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             rb = make_raybox(lo, ld);
             if (NODE32) rb = quant_slab(rb, lmesh->qbase, lmesh->qscale);
             bound_s = HPT_INF; *mybest = HPT_KEY_NONE;
-            stk[0] = SENTINEL; sp = 1; ref = lmesh->root_ref;
+            stk.put(0, SENTINEL); sp = 1; ref = lmesh->root_ref;
         }
         if (!LOCAL && need_setup) {
             const f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
@@ -618,7 +638,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 if (box_hit(rb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), ht * HPT_SLACK, tin)) {
                     if (NODE32) rb = quant_slab(rb, mesh->qbase, mesh->qscale);   // from here on rb addresses the tree's 16-bit grid
                     bound_s = ht * HPT_SLACK; *mybest = HPT_KEY_NONE;
-                    stk[0] = SENTINEL; sp = 1; ref = mesh->root_ref;
+                    stk.put(0, SENTINEL); sp = 1; ref = mesh->root_ref;
                     break;
                 }
                 ++mpos;
@@ -635,18 +655,18 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             if (ref >= 0) {
                 if (COUNT) n_int++;
                 bool hitL, hitR; float tinL, tinR; int l, r;
-                test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r, (HPT_LDS_TOPCACHE && !LOCAL && !NODE32) ? L.top : nullptr);
+                test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r, (HPT_LDS_TOPCACHE && !LOCAL) ? L.top : nullptr);
                 cl = hitL ? min(l, 0) : 0; cr = hitR ? min(r, 0) : 0;
                 const bool intL = hitL && l >= 0, intR = hitR && r >= 0;
                 // flat form (two one-level predicated LDS operations instead of a three-level branch nest)
                 const bool lfirst = intL && (!intR || tinL < tinR);
                 int next = lfirst ? l : r;
-                if (intL && intR) { stk[sp * HPT_BLOCK] = lfirst ? r : l; sp++; }
-                if (!(intL || intR)) { --sp; next = stk[sp * HPT_BLOCK]; }
+                if (intL && intR) { stk.put(sp, lfirst ? r : l); sp++; }
+                if (!(intL || intR)) { --sp; next = stk.get(sp); }
                 ref = next;
             } else if (ref != SENTINEL) {      // a mesh whose root is a leaf
                 cl = ref;
-                --sp; ref = stk[sp * HPT_BLOCK];
+                --sp; ref = stk.get(sp);
             }
             // leaf children join the pending list: left ones, then right ones, a batch tested whenever 64 are pending --
             // at most 63 + 64 entries at any time (HPT_LEAF_CAP 128)
@@ -977,17 +997,19 @@ k_raygen(DScene sc, DPass ps) {
 // DYN: input pieces come through the work counter of this depth (always for the two-level path; for the instance-list
 // path when the rays are expensive -- big trees -- see extend_kernel)
 template <bool COUNT, bool TLAS, bool NODE32, bool DEFER, bool DYN>
-__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : HPT_EXTEND_WAVES, TLAS ? 4 : HPT_EXTEND_WAVES)))
+__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : (DYN ? HPT_EXTEND_WAVES : HPT_EXTEND16_WAVES), TLAS ? 4 : (DYN ? HPT_EXTEND_WAVES : HPT_EXTEND16_WAVES))))
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
-    Lds L = TLAS ? lds_carve_tlas(stack_entries, DEFER) : lds_carve(stack_entries);
+    // instance-list path with the static piece feed = scenes of fewer than 65 536 nodes (extend_dynamic): 16-bit stack entries
+    constexpr bool STK16 = !TLAS && !DYN;
+    Lds L = TLAS ? lds_carve_tlas(stack_entries, DEFER) : lds_carve(stack_entries, STK16);
     L.refill = refill;
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
     wv.work = ps.counts + HPT_WORK_COUNTER(depth);
     unsigned n_int = 0, n_tri = 0, n_inst = 0;
 #if HPT_LDS_TOPCACHE
-    if constexpr (!TLAS && !NODE32) {      // (valid for scenes whose first tree holds the records: the one-mesh teapot frame of the A/B)
-        const int n = min(HPT_LDS_TOPCACHE, sc.n_nodes) * HPT_NODE_QUADS;
+    if constexpr (!TLAS) {      // (valid for scenes whose first tree holds the records: the one-mesh teapot frame of the A/B)
+        const int n = min(HPT_LDS_TOPCACHE, sc.n_nodes) * (NODE32 ? 2 : HPT_NODE_QUADS);
         for (int j = threadIdx.x; j < n; j += HPT_BLOCK) L.top[j] = sc.nodes[j];
         __syncthreads();
     }
@@ -995,7 +1017,7 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     else {
         wv.counts = ps.counts + HPT_MQ_COUNTS(depth);      // instance-list path: the input is the mesh queue k_extend_a filled
-        block_closest_hit<COUNT, NODE32, false, DYN>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+        block_closest_hit<COUNT, NODE32, false, DYN, STK16>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     }
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
@@ -1465,9 +1487,9 @@ static inline int carve_entries(int stack_entries, bool tlas) { return tlas ? st
 // dynamic LDS of the traversal kernels (see lds_carve / lds_carve_tlas): the stack alone, + rings and the
 // deferred-triangle areas (instance-list path), or + key and pending list of deferred analytic instances (two-level path)
 enum { LDS_STACK = 0, LDS_LIST = 1, LDS_TLAS = 2 };
-static inline size_t trav_lds_bytes(int stack_entries, int mode) {
-    size_t n = (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16;
-    if (mode == LDS_LIST) n += (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 + (HPT_LDS_TOPCACHE ? 16 + (size_t)HPT_LDS_TOPCACHE * 64 : 0);
+static inline size_t trav_lds_bytes(int stack_entries, int mode, bool stk16 = false) {
+    size_t n = (size_t)stack_entries * HPT_BLOCK * (stk16 ? sizeof(uint16_t) : sizeof(int)) + 16;
+    if (mode == LDS_LIST) n += (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 + (HPT_LDS_TOPCACHE ? 16 + (size_t)HPT_LDS_TOPCACHE * 32 : 0);
     if (mode == LDS_TLAS) n += (size_t)HPT_BLOCK * 8 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 4;
     return n;
 }
@@ -1553,7 +1575,7 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     HptkPlan p;
     p.extend_entries = carve_entries(stack_entries, sc.use_tlas != 0);
     p.extend_mode = scene_lds_mode(p.extend_entries, sc);
-    p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode);
+    p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode, !sc.use_tlas && !extend_dynamic(sc));      // (static feed <=> k_extend's STK16)
     p.extend_per_cu = extend_resident(sc, p.extend_mode == LDS_TLAS, p.extend_lds);
     p.analytic_per_cu = resident_blocks(k_extend_a<false>, 0);
     p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);

@@ -17,8 +17,8 @@ def run(name, desc, tree=True, spp=16, S=4, depth=8, bpc=None):
     cst = sc.render_device(out.data_ptr(), want_stats=True, spp=cspp, max_depth=depth, seed=1, spp_per_pass=max(S, cspp), flags=hpt.RENDER_COUNTERS)
     st = sc.render_device(out.data_ptr(), want_stats=True, spp=spp, max_depth=depth, seed=1, spp_per_pass=S, flags=hpt.RENDER_TIME_KERNELS)
     rays = st.rays_primary + st.rays_bounce; cr = cst.rays_primary + cst.rays_bounce
-    print("%-28s total %.3fs %7.1f Mrays/s | analytic %.4f extend %.4f (%.2f Grays/s) shade %.4f | nodes/ray %.2f tris/ray %.2f inst/ray %.1f" % (
-        name, st.seconds_total, rays / st.seconds_total / 1e6, st.seconds_analytic, st.seconds_extend, rays / max(st.seconds_extend + st.seconds_analytic, 1e-9) / 1e9, st.seconds_shade,
+    print("%-28s total %.3fs %7.1f Mrays/s | analytic %.4f extend %.4f (%.2f Grays/s) shade %.4f (%.1f ps/ray) | nodes/ray %.2f tris/ray %.2f inst/ray %.1f" % (
+        name, st.seconds_total, rays / st.seconds_total / 1e6, st.seconds_analytic, st.seconds_extend, rays / max(st.seconds_extend + st.seconds_analytic, 1e-9) / 1e9, st.seconds_shade, st.seconds_shade / rays * 1e12,
         cst.nodes_visited / cr, cst.tris_tested / cr, cst.inst_tests / cr), flush=True)
     sc.close()
 
@@ -34,6 +34,9 @@ def main():
         elif w == "noteapot":
             d.nodes = [n for n in d.nodes if n.geom != 3]; d.meshes = []
             run("no teapot", d)
+        elif w == "wallsonly":
+            d.nodes = [n for n in d.nodes if n.geom not in (1, 3)]; d.meshes = []
+            run("planes only", d)
         elif w == "nosphere":
             d.nodes = [n for n in d.nodes if n.geom != 1]
             run("no sphere", d)
