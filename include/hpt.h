@@ -209,7 +209,7 @@ int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* 
 /* hpt_render_device for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc.  No counterpart in the reference (its main.rs:55 allocates the frame buffer per run).  Same
  * arguments, same kernels and bit-identical output as hpt_render_device, but the pass buffers (wavefront queues, hit and
- * radiance records, counters, Halton table) come from a static device array of HPT_NOALLOC_SCRATCH_MB (77) MB that each
+ * radiance records, counters, Halton table) come from a static device array of HPT_NOALLOC_SCRATCH_MB (98) MB that each
  * GPU the library runs on holds until the process ends, instead of from hipMalloc: the call allocates nothing (no
  * hipMalloc / hipFree, no stream or event creation).  Limits (HPT_ERR_LIMIT beyond them): the frame has at most
  * HPT_NOALLOC_MAX_PIXELS = 2^19 pixels (the reference's 800 x 600 fits) and a call renders at most HPT_NOALLOC_MAX_SPP =
@@ -218,7 +218,7 @@ int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* 
  * scene): calls that overlap on one GPU race -- serialise them. */
 #define HPT_NOALLOC_MAX_PIXELS (1u << 19)
 #define HPT_NOALLOC_MAX_SPP 4096
-#define HPT_NOALLOC_SCRATCH_MB 77
+#define HPT_NOALLOC_SCRATCH_MB 98
 int hpt_render_device_noalloc(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
                               hpt_render_stats* stats);
 /* One round of the adaptive loop (main.rs:72-99 restricted to a sample range) on DEVICE buffers, for hosts that

@@ -905,11 +905,11 @@ static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps, int 
            &radiance = set ? s->x[set - 1].radiance : s->w_radiance, &counts = set ? s->x[set - 1].counts : s->w_counts;
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(q[a][k].ensure(max_paths * 16));
     CHK(hit.ensure(max_paths * 16)); CHK(hit_inst.ensure(max_paths * 4)); CHK(radiance.ensure(max_paths * 16));
-    if (!s->ds.use_tlas && s->ds.n_mesh_instances > 0) CHK(mq.ensure(max_paths * 8));      // mesh queue of the instance-list path
+    if (!s->ds.use_tlas && s->ds.n_mesh_instances > 0) CHK(mq.ensure(max_paths * 48));      // mesh queue of the instance-list path: items, origins, directions
     CHK(counts.ensure((size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = q[a][0].as<float4>(); ps.q[a].ray_d = q[a][1].as<float4>(); ps.q[a].thr = q[a][2].as<float4>(); }
-    ps.hit = hit.as<float4>(); ps.hit_inst = hit_inst.as<uint32_t>(); ps.mq = mq.as<uint2>(); ps.radiance = radiance.as<float4>();
+    ps.hit = hit.as<float4>(); ps.hit_inst = hit_inst.as<uint32_t>(); ps.mq = mq.as<uint4>(); ps.radiance = radiance.as<float4>();
     ps.counts = counts.as<uint32_t>(); ps.stat = s->w_stat.as<unsigned long long>();
     return HPT_OK;
 }
@@ -943,6 +943,11 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
     // a render that would be ONE big pass runs as two halves, so that two passes can be in flight (results do not depend on the split)
     if (p->spp_per_pass == 0 && S == p->spp && S >= 2 && ctx->overlap > 1 && !per_sample_host && !ev.on && npix * (uint64_t)S >= (16ull << 20))
         S = (S + 1) / 2;
+    // ... and a render of few big passes as more, smaller ones while those stay above 32 M paths: the two streams only overlap
+    // between the first pass's ramp-up and the last one's drain (1080p, 128 spp -- an eighth of the headline frame, the share
+    // of one GPU of eight: 4 passes of 32 spp 160.0 ms, 8 of 16 spp 157.4 ms)
+    if (p->spp_per_pass == 0 && ctx->overlap > 1 && !per_sample_host && !ev.on)
+        while ((p->spp + S - 1) / S < 8 && S >= 2 && npix * (uint64_t)(S / 2) >= (32ull << 20)) S /= 2;
     // Two passes in flight when there are at least two: pass k runs on stream k & 1 with pass buffers of its own.  The
     // per-kernel event timing of HPT_RENDER_TIME_KERNELS needs launches that have the GPU to themselves: one stream then.
     const int n_passes = (p->spp + S - 1) / S;
@@ -1064,7 +1069,7 @@ extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* 
         ps.q[a].thr = (float4*)(base + HPT_NOALLOC_OFF_Q(3 * a + 2));
     }
     ps.hit = (float4*)(base + HPT_NOALLOC_OFF_HIT); ps.radiance = (float4*)(base + HPT_NOALLOC_OFF_RADIANCE);
-    ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.mq = (uint2*)(base + HPT_NOALLOC_OFF_MQ); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
+    ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.mq = (uint4*)(base + HPT_NOALLOC_OFF_MQ); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
     ps.stat = (unsigned long long*)(base + HPT_NOALLOC_OFF_STAT);
     float2* d_halton = (float2*)(base + HPT_NOALLOC_OFF_HALTON);
     // the array keeps the last call's contents: statistics start at zero here, counters and radiance per pass (run_pass)

@@ -58,13 +58,13 @@
 // queue slots: 64 segments, each rounded up to whole 256-path chunks
 #define HPT_NOALLOC_SLOTS ((size_t)HPT_NOALLOC_MAX_PATHS + (size_t)HPT_SHARDS * HPT_BLOCK)
 #define HPT_ALIGN256(x) (((size_t)(x) + 255) & ~(size_t)255)
-// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), mesh queue (8 B), counters, statistics, Halton
+// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), mesh queue (3 x 16 B), counters, statistics, Halton
 #define HPT_NOALLOC_OFF_Q(k) ((size_t)(k) * HPT_ALIGN256(HPT_NOALLOC_SLOTS * 16))
 #define HPT_NOALLOC_OFF_HIT HPT_NOALLOC_OFF_Q(6)
 #define HPT_NOALLOC_OFF_RADIANCE HPT_NOALLOC_OFF_Q(7)
 #define HPT_NOALLOC_OFF_HIT_INST HPT_NOALLOC_OFF_Q(8)
 #define HPT_NOALLOC_OFF_MQ (HPT_NOALLOC_OFF_HIT_INST + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 4))
-#define HPT_NOALLOC_OFF_COUNTS (HPT_NOALLOC_OFF_MQ + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 8))
+#define HPT_NOALLOC_OFF_COUNTS (HPT_NOALLOC_OFF_MQ + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 48))
 #define HPT_NOALLOC_OFF_STAT (HPT_NOALLOC_OFF_COUNTS + HPT_ALIGN256((size_t)HPT_COUNTS_TOTAL * 4))
 #define HPT_NOALLOC_OFF_HALTON (HPT_NOALLOC_OFF_STAT + 256)
 #define HPT_NOALLOC_SCRATCH_BYTES (HPT_NOALLOC_OFF_HALTON + HPT_ALIGN256((size_t)HPT_NOALLOC_MAX_SPP * 8))
@@ -156,7 +156,9 @@ struct DPass {
     DQueue q[2];
     float4* hit;         // (t, u, v, as_float(global tri or -1))
     uint32_t* hit_inst;  // instance | side<<31, HPT_MISS_INST on miss
-    uint2* mq;           // mesh queue of the current depth: (slot, first mesh instance to visit) of the rays that entered a mesh box, sharded like the path queues
+    uint4* mq;           // mesh queue of the current depth, sharded like the path queues: for every ray that entered a mesh box the item
+                         // (slot, first mesh instance to visit, best analytic t, its instance | side), then -- HPT_SHARDS * shard_cap records
+                         // further on each -- the ray's origin and direction (48 B per slot; see block_analytic)
     float4* radiance;    // (L.rgb, 0) of sample s of slot i at [s * n_slots + i] (k_resolve reads it coalesced); zeroed by the pass
     uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2][HPT_SHARDS] live paths per depth and queue segment, HPT_COUNT_STRIDE apart
     uint32_t shard_cap;  // slots per segment (multiple of HPT_BLOCK); a queue holds HPT_SHARDS * shard_cap slots

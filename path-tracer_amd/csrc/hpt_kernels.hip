@@ -420,9 +420,15 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
 // ballot + wave prefix + one atomic per wave.  (World-box culling of the instance list with deferred exact tests was
 // built and measured in round 2 -- commit c4bf446's successor, profiles/r02c_phase1_cull_ab.txt: exact tests per ray
 // 9 -> 2.7, kernel 21 % slower; not kept.)
-template <bool COUNT>
+// FAT (the render passes): a queue item carries everything the traversal needs to start -- (slot, first mesh instance, best
+// analytic t, its instance | side) + the ray itself, as three arrays of 16-B records [items | origins | directions] of
+// mq_shards * mq_cap entries each.  The traversal reads them coalesced, item after item, instead of gathering hit[slot].x,
+// hit_inst[slot], ray_o[slot] and ray_d[slot] -- four divergent pulls that each fetched a 64-B sector for 4..16 bytes and sat
+// behind the item load (r02e: 229 B of physical traffic per walked ray, most of k_extend's).  Thin items (slot, first mesh
+// instance) stay for the test entries.
+template <bool COUNT, bool FAT = false>
 __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView& wv, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                               float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, uint2* __restrict__ mq,
+                                               float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, void* __restrict__ mq,
                                                uint32_t* __restrict__ mq_counts, uint32_t mq_shards, uint32_t mq_cap, unsigned& n_inst, unsigned& n_queued) {
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t total = input_pieces(wv) / (HPT_BLOCK / 64);      // 256-slot chunks up to the fullest segment
@@ -432,9 +438,11 @@ __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView&
         const uint32_t seg = w % mq_shards;      // (render: the segment the ray came from; one atomic counter per segment: a single one serialises)
         bool queued = false;
         uint2 item = make_uint2(0, 0);
+        float4 o4 = make_float4(0, 0, 0, 0), d4 = o4;
+        Hit a; a.t = HPT_INF; a.inst_side = HPT_MISS_INST;
         if (valid) {
-            Hit a;
-            queued = analytic_phase<COUNT>(sc, xyz(ray_o[i]), xyz(ray_d[i]), i, a, item, n_inst);
+            o4 = ray_o[i]; d4 = ray_d[i];
+            queued = analytic_phase<COUNT>(sc, xyz(o4), xyz(d4), i, a, item, n_inst);
             hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
         }
         const unsigned long long mask = __ballot(queued);
@@ -442,7 +450,14 @@ __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView&
             uint32_t wbase = 0;
             if (lane == 0) wbase = atomicAdd(&mq_counts[seg * HPT_COUNT_STRIDE], (uint32_t)__popcll(mask));
             wbase = __shfl(wbase, 0);
-            if (queued) mq[seg * mq_cap + wbase + lane_prefix(mask)] = item;
+            if (queued) {
+                const uint32_t e = seg * mq_cap + wbase + lane_prefix(mask);
+                if constexpr (FAT) {
+                    const uint32_t n = mq_shards * mq_cap;
+                    ((uint4*)mq)[e] = make_uint4(item.x, item.y, __float_as_uint(a.t), a.inst_side);
+                    ((float4*)mq)[n + e] = o4; ((float4*)mq)[2u * n + e] = d4;
+                } else ((uint2*)mq)[e] = item;
+            }
             if (lane == 0) n_queued += (unsigned)__popcll(mask);
         }
     }
@@ -525,8 +540,8 @@ template <> struct TravStack<true> {
     __device__ __forceinline__ void put(int sp, int ref) { p[sp * HPT_BLOCK] = (uint16_t)ref; }      // the sentinel 0x80000000 is stored as 0... see get
     __device__ __forceinline__ int get(int sp) const { const int v = (int)p[sp * HPT_BLOCK]; return sp == 0 ? (int)0x80000000 : v; }   // entry 0 is always the sentinel
 };
-template <bool COUNT, bool NODE32, bool LOCAL = false, bool DYNAMIC = false, bool STK16 = false>
-__device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const uint2* __restrict__ mq, const float4* __restrict__ ray_o,
+template <bool COUNT, bool NODE32, bool LOCAL = false, bool DYNAMIC = false, bool STK16 = false, bool FAT = false>
+__device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, const WorkView& wv, const void* __restrict__ mq, const float4* __restrict__ ray_o,
                                                   const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                   unsigned& n_int, unsigned& n_tri, unsigned& n_inst,
                                                   const DMesh* lmesh = nullptr, uint8_t* __restrict__ side_out = nullptr) {
@@ -544,6 +559,8 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     unsigned pend = 0;                                        // wave-uniform: pending-list fill
     bool have = false;
     uint32_t slot = 0; int mpos = 0, first_mpos = 0;
+    uint32_t item_at = 0;      // FAT: where the lane's item sits (the world ray is read from there, again for every further mesh instance)
+    const uint32_t mq_n = wv.shards * wv.cap;
     f3 lo = mk3(0, 0, 0), ld = mk3(0, 0, 1);
     float ht = HPT_INF; uint32_t hinst = HPT_MISS_INST;      // scene-level nearest so far of the lane's ray (t, instance | side)
     RayBox rb = make_raybox(lo, ld);
@@ -570,10 +587,16 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             const uint32_t left = piece_n - piece_pos, nidle = (uint32_t)__popcll(idle), take = nidle < left ? nidle : left;
             const uint32_t rank = lane_prefix(idle);
             if (!have && rank < take) {
-                const uint2 it = mq[piece_slot + piece_pos + rank];
-                slot = it.x; mpos = first_mpos = (int)it.y;
-                // the best analytic hit of the ray comes from hit[] / hit_inst[] (written by the analytic stage's launch)
-                if constexpr (!LOCAL) { ht = hit[slot].x; hinst = hit_inst[slot]; }
+                if constexpr (FAT) {      // the best analytic hit of the ray travels in the item
+                    item_at = piece_slot + piece_pos + rank;
+                    const uint4 it = ((const uint4*)mq)[item_at];
+                    slot = it.x; mpos = first_mpos = (int)it.y; ht = __uint_as_float(it.z); hinst = it.w;
+                } else {
+                    const uint2 it = ((const uint2*)mq)[piece_slot + piece_pos + rank];
+                    slot = it.x; mpos = first_mpos = (int)it.y;
+                    // ... or comes from hit[] / hit_inst[] (written by the analytic stage's launch)
+                    if constexpr (!LOCAL) { ht = hit[slot].x; hinst = hit_inst[slot]; }
+                }
                 have = true; need_setup = true;
             }
             piece_pos += take;
@@ -619,7 +642,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             stk.put(0, SENTINEL); sp = 1; ref = lmesh->root_ref;
         }
         if (!LOCAL && need_setup) {
-            const f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
+            const f3 o = xyz(FAT ? ((const float4*)mq)[mq_n + item_at] : ray_o[slot]), d = xyz(FAT ? ((const float4*)mq)[2u * mq_n + item_at] : ray_d[slot]);
             for (;;) {
                 if (mpos >= sc.n_mesh_instances) { have = false; ref = SENTINEL; break; }      // hit[slot] is final
                 inst_idx = sc.mesh_instances[mpos];
@@ -1017,7 +1040,7 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     else {
         wv.counts = ps.counts + HPT_MQ_COUNTS(depth);      // instance-list path: the input is the mesh queue k_extend_a filled
-        block_closest_hit<COUNT, NODE32, false, DYN, STK16>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+        block_closest_hit<COUNT, NODE32, false, DYN, STK16, true>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     }
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
@@ -1033,7 +1056,7 @@ k_extend_a(DScene sc, DPass ps, int depth) {
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.work = nullptr;
     unsigned n_inst = 0, n_queued = 0;
-    block_analytic<COUNT>(sc, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, ps.mq, ps.counts + HPT_MQ_COUNTS(depth), HPT_SHARDS, ps.shard_cap, n_inst, n_queued);
+    block_analytic<COUNT, true>(sc, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, ps.mq, ps.counts + HPT_MQ_COUNTS(depth), HPT_SHARDS, ps.shard_cap, n_inst, n_queued);
     const unsigned long long nq = wave_sum<unsigned long long>(n_queued);
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&ps.stat[5], nq);
     if (COUNT) {

@@ -124,7 +124,7 @@ extern "C" {
                       stats: *mut hpt_render_stats) -> c_int;
     pub fn hpt_render_device(scene: *mut hpt_scene, params: *const hpt_render_params, rgb_sum_device: *mut f32,
                              stats: *mut hpt_render_stats) -> c_int;
-    /// `hpt_render_device` for callers that cannot allocate: pass buffers from a static 77 MB device array, at most 2^19
+    /// `hpt_render_device` for callers that cannot allocate: pass buffers from a static 98 MB device array, at most 2^19
     /// pixels and 4096 samples per call; calls that overlap on one GPU race.
     pub fn hpt_render_device_noalloc(scene: *mut hpt_scene, params: *const hpt_render_params, rgb_sum_device: *mut f32,
                                      stats: *mut hpt_render_stats) -> c_int;
