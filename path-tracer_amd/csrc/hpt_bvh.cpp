@@ -386,6 +386,40 @@ bool flatten_tree(const HostTree& tree, const float* leaf_boxes, int32_t nleaf, 
         for (int32_t c : {tree.left[i], tree.right[i]})
             if (tree.prim[c] < 0) { depth[c] = depth[i] + 1; queue.push_back(c); }
     }
+    // Numbering of the interior nodes = their order in memory.  Breadth-first puts a node's record between those of its
+    // cousins: a ray walking DOWN finds nothing it needs in the 128-B line a fetch brought in (4 Node32 / 2 Node64 records).
+    // Treelet order: starting at a subtree root, up to 4 interior nodes -- the root, then repeatedly the frontier node with
+    // the largest surface area, i.e. the one a ray that is here most probably visits next -- get consecutive indices, and
+    // the subtrees hanging off the treelet follow depth-first, largest first, so a subtree stays contiguous at every scale
+    // (L1 / L2 lines, Infinity Cache pages).  Traversal and hits do not depend on the numbering.  Measured (r02g): the
+    // 1 M-triangle soup, whose 32 MB of nodes miss L2, k_extend -5.6 % (frame +3.6 %); trees that live in L2 +-0 (teapot,
+    // 3 375 instanced teapots, the TLAS of 10 k spheres) -- so trees below 65 536 interior nodes keep the breadth-first
+    // numbering.  HPT_NODE_ORDER=bfs / treelet forces one (A/B runs; the HPT_LDS_TOPCACHE variant of the kernels assumes bfs).
+    {
+        const char* e = getenv("HPT_NODE_ORDER");
+        const bool treelet = e ? strcmp(e, "treelet") == 0 : out.n_interior >= 65536;
+        if (treelet && out.n_interior > 4) {
+            auto area = [&](int32_t i) { const Box& b = box[i]; const double dx = (double)b.mx[0] - b.mn[0], dy = (double)b.mx[1] - b.mn[1], dz = (double)b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
+            std::vector<int32_t> roots{tree.root}, frontier;
+            int32_t next = 0;
+            while (!roots.empty()) {
+                const int32_t r = roots.back(); roots.pop_back();
+                frontier.clear();
+                int32_t taken = 0, cur = r;
+                for (;;) {
+                    bfs_index[cur] = next++; ++taken;
+                    for (int32_t c : {tree.left[cur], tree.right[cur]}) if (tree.prim[c] < 0) frontier.push_back(c);
+                    if (taken == 4 || frontier.empty()) break;
+                    size_t best = 0;
+                    for (size_t k = 1; k < frontier.size(); ++k) if (area(frontier[k]) > area(frontier[best])) best = k;
+                    cur = frontier[best]; frontier.erase(frontier.begin() + (ptrdiff_t)best);
+                }
+                // the rest of the frontier: roots of the next treelets, the largest on top of the stack (numbered next)
+                std::sort(frontier.begin(), frontier.end(), [&](int32_t a, int32_t b) { return area(a) < area(b); });
+                for (int32_t c : frontier) roots.push_back(c);
+            }
+        }
+    }
     auto ref_of = [&](int32_t i) -> int32_t { return tree.prim[i] >= 0 ? ~tree.prim[i] : bfs_index[i]; };
     out.root_ref = ref_of(tree.root);
     out.nodes.assign((size_t)out.n_interior * 16, 0.0f);

@@ -14,6 +14,7 @@
 // boxes are conservative supersets of their triangles).  MFMA is not used: there is no dense contraction here.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <stdint.h>
 #include "hpt_device.h"
@@ -1019,11 +1020,10 @@ k_raygen(DScene sc, DPass ps) {
 // DEFER (two-level only): analytic instances go through the pending list (the launch then carves key + list in LDS)
 // DYN: input pieces come through the work counter of this depth (always for the two-level path; for the instance-list
 // path when the rays are expensive -- big trees -- see extend_kernel)
-template <bool COUNT, bool TLAS, bool NODE32, bool DEFER, bool DYN>
-__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : (DYN ? HPT_EXTEND_WAVES : HPT_EXTEND16_WAVES), TLAS ? 4 : (DYN ? HPT_EXTEND_WAVES : HPT_EXTEND16_WAVES))))
+template <bool COUNT, bool TLAS, bool NODE32, bool DEFER, bool DYN, bool STK16 = false>
+__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES), TLAS ? 4 : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES))))
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
-    // instance-list path with the static piece feed = scenes of fewer than 65 536 nodes (extend_dynamic): 16-bit stack entries
-    constexpr bool STK16 = !TLAS && !DYN;
+    // STK16 (instance-list path, scenes of fewer than 65 535 nodes): 16-bit stack entries
     Lds L = TLAS ? lds_carve_tlas(stack_entries, DEFER) : lds_carve(stack_entries, STK16);
     L.refill = refill;
     const DQueue& q = ps.q[depth & 1];
@@ -1528,10 +1528,18 @@ static int resident_blocks(K k, size_t lds) {
 }
 // The instance-list kernel takes its input through the work counter when the scene's trees are big (rays cost tens of
 // steps: 1 M-triangle soup -4 %), and keeps the static stride when they are small (teapot: the counter costs +16 %).
-static inline bool extend_dynamic(const DScene& sc) { return sc.n_nodes >= 65536; }
+static inline bool extend_dynamic(const DScene& sc) {
+    static const int forced = [] { const char* e = getenv("HPT_EXTEND_DYNAMIC"); return e ? atoi(e) : -1; }();
+    return forced >= 0 ? forced != 0 : sc.n_nodes >= 65536;
+}
+static inline bool extend_stk16(const DScene& sc) { return !sc.use_tlas && sc.n_nodes < 65535; }      // every interior ref fits 16 bits beside the 0xffff that is never one
 template <bool COUNT>
 static auto extend_kernel(const DScene& sc, bool defer) -> void (*)(DScene, DPass, int, int, int) {
     if (!sc.use_tlas) {
+        if (extend_stk16(sc)) {
+            if (extend_dynamic(sc)) return sc.node32 ? k_extend<COUNT, false, true, false, true, true> : k_extend<COUNT, false, false, false, true, true>;
+            return sc.node32 ? k_extend<COUNT, false, true, false, false, true> : k_extend<COUNT, false, false, false, false, true>;
+        }
         if (extend_dynamic(sc)) return sc.node32 ? k_extend<COUNT, false, true, false, true> : k_extend<COUNT, false, false, false, true>;
         return sc.node32 ? k_extend<COUNT, false, true, false, false> : k_extend<COUNT, false, false, false, false>;
     }
@@ -1598,7 +1606,7 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     HptkPlan p;
     p.extend_entries = carve_entries(stack_entries, sc.use_tlas != 0);
     p.extend_mode = scene_lds_mode(p.extend_entries, sc);
-    p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode, !sc.use_tlas && !extend_dynamic(sc));      // (static feed <=> k_extend's STK16)
+    p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode, extend_stk16(sc));
     p.extend_per_cu = extend_resident(sc, p.extend_mode == LDS_TLAS, p.extend_lds);
     p.analytic_per_cu = resident_blocks(k_extend_a<false>, 0);
     p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
