@@ -101,7 +101,7 @@ struct hpt_scene {
     bool have_camera = false, committed = false;
     uint64_t generation = 0;    // commits so far (a group re-replicates a scene that was committed again)
     // device side
-    DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_instboxes, d_meshinst, d_xinv, d_xfwd, d_materials, d_images, d_pool;
+    DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_meshinst, d_xinv, d_xfwd, d_materials, d_images, d_pool;
     std::vector<DMesh> h_meshes;
     DScene ds;
     int stack_entries = 1;
@@ -266,7 +266,7 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (hipStream_t a : s->ctx->aux_stream) if (a) (void)hipStreamSynchronize(a);   // (joined already unless a render failed half way)
-    DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_instboxes, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_materials,
+    DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_materials,
                      &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_mq, &s->t_mq, &s->t_mqcount, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
                      &s->w_accum, &s->w_minmax, &s->w_spp, &s->w_list[0], &s->w_list[1], &s->w_listcount, &s->w_out,
                      &s->t_org, &s->t_dir, &s->t_hit, &s->t_side};
@@ -539,9 +539,8 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     int32_t use_tlas = 0, tlas_root = 0;
     s->tlas_nodes = 0;
     QuantFrame tlas_qf; std::memset(&tlas_qf, 0, sizeof tlas_qf);
-    // padded world boxes of the instances: leaves of the TLAS, and what phase 1 of the instance-list kernel culls with
+    // padded world boxes of the instances: leaves of the TLAS
     std::vector<float> wb(inst.size() * 6);
-    std::vector<DInstBox> iboxes(inst.size());
     {
         for (size_t i = 0; i < inst.size(); ++i) {
             const DInstance& di = inst[i];
@@ -569,9 +568,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
             for (int k = 0; k < 3; ++k) {
                 if ((double)wb[6 * i + k] > mn[k] - pad) wb[6 * i + k] = std::nextafterf(wb[6 * i + k], -INFINITY);
                 if ((double)wb[6 * i + 3 + k] < mx[k] + pad) wb[6 * i + 3 + k] = std::nextafterf(wb[6 * i + 3 + k], INFINITY);
-                iboxes[i].mn[k] = wb[6 * i + k]; iboxes[i].mx[k] = wb[6 * i + 3 + k];
             }
-            iboxes[i].geom = di.geom; iboxes[i].pad = 0;
         }
     }
     if ((int)inst.size() >= tlas_min && inst.size() >= 2) {      // (>= 2: the root of the TLAS is an interior node)
@@ -642,13 +639,13 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     if (node32) CHK(upload(s->d_nodes, nodes32, st)); else CHK(upload(s->d_nodes, nodes, st));
     s->node_bytes = node32 ? 32 : 64;
     CHK(upload(s->d_tris, tris, st)); CHK(upload(s->d_trishade, trishade, st));
-    CHK(upload(s->d_meshes, s->h_meshes, st)); CHK(upload(s->d_instances, inst, st)); CHK(upload(s->d_instboxes, iboxes, st)); CHK(upload(s->d_meshinst, meshinst, st));
+    CHK(upload(s->d_meshes, s->h_meshes, st)); CHK(upload(s->d_instances, inst, st)); CHK(upload(s->d_meshinst, meshinst, st));
     CHK(upload(s->d_xinv, xinv, st)); CHK(upload(s->d_xfwd, xfwd, st));
     CHK(upload(s->d_materials, mats, st)); CHK(upload(s->d_images, imgs, st)); CHK(upload(s->d_pool, pool, st));
     HIPCHK(hipStreamSynchronize(st));   // the staging vectors die at scope end
     DScene& d = s->ds;
     d.nodes = s->d_nodes.as<float4>(); d.tris = s->d_tris.as<float4>(); d.trishade = s->d_trishade.as<float4>();
-    d.meshes = s->d_meshes.as<DMesh>(); d.instances = s->d_instances.as<DInstance>(); d.inst_boxes = s->d_instboxes.as<DInstBox>(); d.mesh_instances = s->d_meshinst.as<int32_t>();
+    d.meshes = s->d_meshes.as<DMesh>(); d.instances = s->d_instances.as<DInstance>(); d.mesh_instances = s->d_meshinst.as<int32_t>();
     d.xinv = s->d_xinv.as<DXformInv>(); d.xfwd = s->d_xfwd.as<DXformFwd>();
     d.materials = s->d_materials.as<DMaterial>(); d.images = s->d_images.as<DImage>(); d.image_pool = s->d_pool.as<uint8_t>();
     d.n_instances = (int32_t)inst.size(); d.n_meshes = (int32_t)s->h_meshes.size();

@@ -44,11 +44,6 @@
 #ifndef HPT_PIECE_BATCH
 #define HPT_PIECE_BATCH 8
 #endif
-#ifndef HPT_QUEUE_CAP
-#define HPT_QUEUE_CAP 512
-#endif
-//      HPT_QUEUE_CAP         // LDS ray rings of k_extend, one per wave (HPT_QUEUE_CAP / 4 items each: < 64 left + 64 appended):
-//                            // rays that entered a mesh box, waiting for traversal
 
 // ---- static workspace of hpt_render_device_noalloc (hpt_kernels.hip `scratch`) ----
 #define HPT_NOALLOC_MAX_PATHS (1u << 19)   // pixels of the largest frame it renders (one sample of every pixel per pass; the reference's 800 x 600 fits)
@@ -95,11 +90,6 @@ struct DInstance {   // one Node with an object, in the reference's DFS visiting
     DXformInv lv[2];              // inline copy of chain levels 0 and 1 (deeper levels: xinv[xf_first + k])
 };
 
-struct DInstBox {    // padded world-space box of an instance (what the TLAS is built over; phase 1 of the instance-list kernel culls with it)
-    float mn[3]; int32_t geom;
-    float mx[3]; int32_t pad;
-};
-
 struct DTexture {
     int32_t kind, image;
     float color[3], color1[3], color2[3];
@@ -130,7 +120,6 @@ struct DScene {
     const float4* trishade;
     const DMesh* meshes;
     const DInstance* instances;
-    const DInstBox* inst_boxes;      // [n_instances]
     const int32_t* mesh_instances;   // indices (into instances[]) of the mesh instances, ascending
     const DXformInv* xinv;
     const DXformFwd* xfwd;

@@ -284,7 +284,6 @@ struct Hit { float t, u, v; int prim; uint32_t inst_side; };
 //  wait per step costs more than the fetches it saves)
 struct Lds {
     int* stack;          // per-lane traversal stack, lane's column = stack + threadIdx.x, stride HPT_BLOCK
-    uint2* queue;        // (unused since the analytic stage became a launch of its own: rays come from the mesh queue in global memory)
     int refill;          // idle lanes at which a wave leaves its traversal loop to refill
     bool defer;          // two-level path: analytic instances go through the pending list
     // deferred tests: per lane the best key of the ray it owns (t | triangle, or t | instance | side) + u, v, side of
@@ -298,7 +297,6 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries, bool stk16 = false) 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds L;
     L.stack = (int*)lds_raw;
-    L.queue = nullptr;
     L.best = (unsigned long long*)(lds_raw + (size_t)stack_entries * HPT_BLOCK * (stk16 ? sizeof(uint16_t) : sizeof(int)) + 16);
     L.du = (float*)(L.best + HPT_BLOCK);
     L.dv = L.du + HPT_BLOCK;
@@ -1507,7 +1505,7 @@ static inline int grid_for(uint64_t n, int max_blocks) {
 // stack entries the traversal kernels carve: the instance-list path never pushes a leaf (leaf children go to the pending
 // list), so it needs one entry less than the two-level path, whose count the host hands over
 static inline int carve_entries(int stack_entries, bool tlas) { return tlas ? stack_entries : (stack_entries > 2 ? stack_entries - 1 : stack_entries); }
-// dynamic LDS of the traversal kernels (see lds_carve / lds_carve_tlas): the stack alone, + rings and the
+// dynamic LDS of the traversal kernels (see lds_carve / lds_carve_tlas): the stack alone, + the
 // deferred-triangle areas (instance-list path), or + key and pending list of deferred analytic instances (two-level path)
 enum { LDS_STACK = 0, LDS_LIST = 1, LDS_TLAS = 2 };
 static inline size_t trav_lds_bytes(int stack_entries, int mode, bool stk16 = false) {
