@@ -27,9 +27,6 @@
 #endif
 #ifndef HPT_SHADE_WAVES
 #define HPT_EXTEND16_WAVES 7     // the same kernel with 16-bit stack entries (scenes below 65 536 nodes): 16.5 KB of LDS, 7 workgroups per CU by its registers
-#ifndef HPT_TLAS_WAVES
-#define HPT_TLAS_WAVES 4         // two-level kernel: 101..118 VGPRs
-#endif
 #define HPT_SHADE_WAVES 7
 #endif
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
@@ -1022,7 +1019,7 @@ k_raygen(DScene sc, DPass ps) {
 // DYN: input pieces come through the work counter of this depth (always for the two-level path; for the instance-list
 // path when the rays are expensive -- big trees -- see extend_kernel)
 template <bool COUNT, bool TLAS, bool NODE32, bool DEFER, bool DYN, bool STK16 = false>
-__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? HPT_TLAS_WAVES : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES), TLAS ? HPT_TLAS_WAVES : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES))))
+__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES), TLAS ? 4 : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES))))
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     // STK16 (instance-list path, scenes of fewer than 65 535 nodes): 16-bit stack entries
     Lds L = TLAS ? lds_carve_tlas(stack_entries, DEFER) : lds_carve(stack_entries, STK16);
