@@ -571,7 +571,9 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
             }
         }
     }
-    if ((int)inst.size() >= tlas_min && inst.size() >= 2) {      // (>= 2: the root of the TLAS is an interior node)
+    // (mesh-queue items of the instance-list path carry the mesh and the position in mesh_instances[] in 16 bits each)
+    const bool list_limits = meshinst.size() >= 65536 || s->h_meshes.size() >= 65536;
+    if (((int)inst.size() >= tlas_min || list_limits) && inst.size() >= 2) {      // (>= 2: the root of the TLAS is an interior node)
         HostTree tt; FlatMesh ft; std::string err;
         tree_build_sah_boxes(wb.data(), (int32_t)inst.size(), tt);
         if (topt.mode != 0 && (int32_t)inst.size() <= topt.max_leaves_for_passes)

@@ -25,8 +25,10 @@
 #ifndef HPT_EXTEND_WAVES
 #define HPT_EXTEND_WAVES 6       // mesh-queue traversal kernel: 71 VGPRs, 6 workgroups per CU by its 25.5 KB of LDS (18 stack entries); the two-level kernel (101..118 VGPRs) stays at 4
 #endif
-#ifndef HPT_SHADE_WAVES
+#ifndef HPT_EXTEND16_WAVES
 #define HPT_EXTEND16_WAVES 7     // the same kernel with 16-bit stack entries (scenes below 65 536 nodes): 16.5 KB of LDS, 7 workgroups per CU by its registers
+#endif
+#ifndef HPT_SHADE_WAVES
 #define HPT_SHADE_WAVES 7
 #endif
 #define HPT_SHADE_OCC __attribute__((amdgpu_waves_per_eu(HPT_SHADE_WAVES, HPT_SHADE_WAVES)))
@@ -37,6 +39,12 @@
 #endif
 #ifndef HPT_PARK_TRI
 #define HPT_PARK_TRI 12
+#endif
+// Pending list of the instance-list traversal as a FIFO ring that SURVIVES refills (A/B variant, see block_closest_hit): 0 = the
+// list is emptied -- as a partial batch -- before every refill; N > 0 = entries stay pending across refills, a lane whose mesh is
+// finished retires once its own entries have been tested, and a partial batch runs only when fewer than N lanes could be refilled
+#ifndef HPT_PEND_FIFO
+#define HPT_PEND_FIFO 0
 #endif
 #ifndef HPT_PARK_INST
 #define HPT_PARK_INST 12
@@ -377,10 +385,12 @@ template <> struct PieceFeed<false> {
 };
 
 // phase 1 for one ray: analytic instances + first mesh box entered.  Returns true when the ray must be queued.
+// item.y = position of that instance in mesh_instances[] | its mesh << 16 (instance-list scenes hold fewer than 65 536 of either:
+// hpt_scene_commit switches to the two-level path beyond that); mlo / mld = the ray in the space of that mesh.
 template <bool COUNT>
-__device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uint32_t slot, Hit& h, uint2& item, unsigned& n_inst) {
+__device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uint32_t slot, Hit& h, uint2& item, unsigned& n_inst, f3& mlo, f3& mld) {
     h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
-    int mpos = -1, mcount = 0;
+    int mpos = -1, mcount = 0, mmesh = 0;
     f3 lo0 = o, ld0 = d;
     for (int k = 0; k < sc.n_instances; ++k) {
         const DInstance in = load_uniform(sc.instances, k);      // wave-uniform record: scalar loads
@@ -393,7 +403,7 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
                 const DMesh mesh = load_uniform(sc.meshes, in.mesh);
                 const RayBox rb = make_raybox(lo, ld);
                 float tin;
-                if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin)) mpos = mcount;
+                if (box_hit(rb, make_float3(mesh.bmin[0], mesh.bmin[1], mesh.bmin[2]), make_float3(mesh.bmax[0], mesh.bmax[1], mesh.bmax[2]), HPT_INF, tin)) { mpos = mcount; mmesh = in.mesh; mlo = lo; mld = ld; }
             }
             mcount++;
         } else {
@@ -405,7 +415,7 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
             if (ok && t < h.t) { h.t = t; h.inst_side = (uint32_t)k | ((uint32_t)s << 31); }   // ascending k: earlier wins ties
         }
     }
-    if (mpos >= 0) { item = make_uint2(slot, (uint32_t)mpos); return true; }   // the analytic result travels in hit[slot]
+    if (mpos >= 0) { item = make_uint2(slot, (uint32_t)mpos | ((uint32_t)mmesh << 16)); return true; }   // the analytic result travels in hit[slot]
     return false;
 }
 
@@ -419,8 +429,10 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
 // ballot + wave prefix + one atomic per wave.  (World-box culling of the instance list with deferred exact tests was
 // built and measured in round 2 -- commit c4bf446's successor, profiles/r02c_phase1_cull_ab.txt: exact tests per ray
 // 9 -> 2.7, kernel 21 % slower; not kept.)
-// FAT (the render passes): a queue item carries everything the traversal needs to start -- (slot, first mesh instance, best
-// analytic t, its instance | side) + the ray itself, as three arrays of 16-B records [items | origins | directions] of
+// FAT (the render passes): a queue item carries everything the traversal needs to start -- (slot, first mesh instance | its mesh
+// << 16, best analytic t, its instance | side) + the ray IN THE SPACE OF THAT MESH (this stage has just computed it for the root-box
+// test: the traversal's per-ray setup -- done with the 24..40 lanes a refill feeds -- then needs no transform chain and no instance
+// record; r02g carried the world ray and the setup re-ran the chain), as three arrays of 16-B records [items | origins | directions] of
 // mq_shards * mq_cap entries each.  The traversal reads them coalesced, item after item, instead of gathering hit[slot].x,
 // hit_inst[slot], ray_o[slot] and ray_d[slot] -- four divergent pulls that each fetched a 64-B sector for 4..16 bytes and sat
 // behind the item load (r02e: 229 B of physical traffic per walked ray, most of k_extend's).  Thin items (slot, first mesh
@@ -437,11 +449,11 @@ __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView&
         const uint32_t seg = w % mq_shards;      // (render: the segment the ray came from; one atomic counter per segment: a single one serialises)
         bool queued = false;
         uint2 item = make_uint2(0, 0);
-        float4 o4 = make_float4(0, 0, 0, 0), d4 = o4;
+        f3 mlo = mk3(0, 0, 0), mld = mk3(0, 0, 1);
         Hit a; a.t = HPT_INF; a.inst_side = HPT_MISS_INST;
         if (valid) {
-            o4 = ray_o[i]; d4 = ray_d[i];
-            queued = analytic_phase<COUNT>(sc, xyz(o4), xyz(d4), i, a, item, n_inst);
+            const float4 o4 = ray_o[i], d4 = ray_d[i];
+            queued = analytic_phase<COUNT>(sc, xyz(o4), xyz(d4), i, a, item, n_inst, mlo, mld);
             hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
         }
         const unsigned long long mask = __ballot(queued);
@@ -454,7 +466,7 @@ __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView&
                 if constexpr (FAT) {
                     const uint32_t n = mq_shards * mq_cap;
                     ((uint4*)mq)[e] = make_uint4(item.x, item.y, __float_as_uint(a.t), a.inst_side);
-                    ((float4*)mq)[n + e] = o4; ((float4*)mq)[2u * n + e] = d4;
+                    ((float4*)mq)[n + e] = make_float4(mlo.x, mlo.y, mlo.z, 0.0f); ((float4*)mq)[2u * n + e] = make_float4(mld.x, mld.y, mld.z, 0.0f);
                 } else ((uint2*)mq)[e] = item;
             }
             if (lane == 0) n_queued += (unsigned)__popcll(mask);
@@ -468,12 +480,15 @@ __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView&
 // hit and, on equal t, the lower triangle index (order-independent, hence deterministic; the reference's "later visited wins" depends on its
 // own tree and north_star excludes edge rays).  The lane whose key
 // is the minimum afterwards leaves u, v and the side beside it (LDS operations of one wave execute in order).
-template <bool COUNT>
+template <bool COUNT, bool RING = false>
 __device__ __forceinline__ void test_pending(const Lds& L, const float4* __restrict__ tris, unsigned first, unsigned n,
                                              f3 lo, f3 ld, unsigned& n_tri) {
     const unsigned lane = threadIdx.x & 63u, wbase = threadIdx.x & ~63u, wave = threadIdx.x >> 6;
     const bool act = lane < n;
-    const unsigned e = wave * HPT_LEAF_CAP + first + (act ? lane : 0u);
+#ifdef HPT_DEBUG_SLOTS
+    if (COUNT && HPT_DEBUG_SLOTS == 5) n_tri += 1000u;      // batches (x 64 x 1000) on top of the tested pairs
+#endif
+    const unsigned e = wave * HPT_LEAF_CAP + (RING ? ((first + (act ? lane : 0u)) & (unsigned)(HPT_LEAF_CAP - 1)) : first + (act ? lane : 0u));
     const uint32_t tri = L.ltri[e];
     const int owner = (int)L.lown[e];
     f3 po, pd;
@@ -556,9 +571,15 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     uint32_t piece_slot = 0, piece_n = 0, piece_pos = 0;      // wave-uniform: the piece items are being handed out from
     bool input_done = false;
     unsigned pend = 0;                                        // wave-uniform: pending-list fill
+#if HPT_PEND_FIFO
+    uint32_t qhead = 0, qtail = 0;      // wave-uniform sequence numbers: entries [qhead, qtail) are pending, entry e sits at ring index e % HPT_LEAF_CAP
+    uint32_t my_last = 0;               // sequence number + 1 of the last entry this lane appended: all of its entries are tested once my_last <= qhead
+#define HPT_FLUSHED (my_last <= qhead)
+#else
+#define HPT_FLUSHED true
+#endif
     bool have = false;
     uint32_t slot = 0; int mpos = 0, first_mpos = 0;
-    uint32_t item_at = 0;      // FAT: where the lane's item sits (the world ray is read from there, again for every further mesh instance)
     const uint32_t mq_n = wv.shards * wv.cap;
     f3 lo = mk3(0, 0, 0), ld = mk3(0, 0, 1);
     float ht = HPT_INF; uint32_t hinst = HPT_MISS_INST;      // scene-level nearest so far of the lane's ray (t, instance | side)
@@ -566,8 +587,43 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
     float bound_s = HPT_INF;      // min(nearest triangle of this mesh as of the last batch, scene-level nearest) * HPT_SLACK
     int ref = SENTINEL, sp = 1, inst_idx = 0;
     for (;;) {
+        // (a round = merge, refill, setup, box steps; r02g pulled before it merged, so a finished lane sat out one whole round)
+        bool need_setup = false, fresh = false;      // fresh: pulled in this round (FAT: the slot holds the ray in the space of its first mesh)
+        bool next_mesh = false;                      // goes on to its next mesh instance (world ray, chain, root box)
+        uint32_t item_at = 0; int first_mesh = 0;    // FAT: where the lane's item sits, and the mesh of its first mesh instance
+        // ---- lanes whose mesh is finished (nothing of theirs is pending) merge its result, then retire -- and take a new item
+        //      in this same round -- or move on to the ray's next mesh instance
+        if (LOCAL && have && ref == SENTINEL && HPT_FLUSHED) {
+            const unsigned long long key = *mybest;
+            if ((uint32_t)key != 0xffffffffu) {
+                const uint32_t sf = L.dsf[threadIdx.x];
+                const float t = (sf & 2u) ? -0.0f : __uint_as_float((uint32_t)(key >> 32));
+                hit[slot] = make_float4(t, L.du[threadIdx.x], L.dv[threadIdx.x], __int_as_float((int)(uint32_t)key - lmesh->tri_base));
+                side_out[slot] = (uint8_t)(sf & 1u);
+            }
+            have = false;
+        }
+        if (!LOCAL && have && ref == SENTINEL && HPT_FLUSHED) {
+            const unsigned long long key = *mybest;
+            if ((uint32_t)key != 0xffffffffu) {
+                const float t = __uint_as_float((uint32_t)(key >> 32));
+                // replaces the scene-level nearest iff t < h.t, or t == h.t and this instance comes EARLIER in the
+                // reference's visiting order than the holder of h.t (scene.rs:196,251 keep the earlier node on equal t)
+                const bool tie_ok = (uint32_t)inst_idx < (hinst & 0x7fffffffu);
+                if (t < ht || (tie_ok && t == ht)) {
+                    // the record in hit[] is brought up to date right away: only t and the instance stay in registers
+                    const uint32_t sf = L.dsf[threadIdx.x];
+                    ht = (sf & 2u) ? -0.0f : t;
+                    hinst = (uint32_t)inst_idx | ((sf & 1u) << 31);
+                    hit[slot] = make_float4(ht, L.du[threadIdx.x], L.dv[threadIdx.x], __int_as_float((int)(uint32_t)key));
+                    hit_inst[slot] = hinst;
+                }
+            }
+            ++mpos;
+            if (mpos >= sc.n_mesh_instances) have = false;      // hit[slot] is final
+            else next_mesh = true;
+        }
         // ---- lanes without a ray take the next items of the queue
-        bool need_setup = false;
         while (!input_done) {
             const unsigned long long idle = __ballot(!have);
             if (idle == 0ull) break;
@@ -589,10 +645,11 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
                 if constexpr (FAT) {      // the best analytic hit of the ray travels in the item
                     item_at = piece_slot + piece_pos + rank;
                     const uint4 it = ((const uint4*)mq)[item_at];
-                    slot = it.x; mpos = first_mpos = (int)it.y; ht = __uint_as_float(it.z); hinst = it.w;
+                    slot = it.x; mpos = first_mpos = (int)(it.y & 0xffffu); first_mesh = (int)(it.y >> 16); ht = __uint_as_float(it.z); hinst = it.w;
+                    fresh = true;
                 } else {
                     const uint2 it = ((const uint2*)mq)[piece_slot + piece_pos + rank];
-                    slot = it.x; mpos = first_mpos = (int)it.y;
+                    slot = it.x; mpos = first_mpos = (int)(it.y & 0xffffu);
                     // ... or comes from hit[] / hit_inst[] (written by the analytic stage's launch)
                     if constexpr (!LOCAL) { ht = hit[slot].x; hinst = hit_inst[slot]; }
                 }
@@ -601,37 +658,10 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             piece_pos += take;
         }
         const bool exhausted = input_done;      // nothing left to pull, ever
-        // ---- lanes whose mesh is finished (nothing of theirs is pending: the list was emptied below) merge its result
-        //      and move on to the ray's next mesh instance
-        if (LOCAL && have && !need_setup && ref == SENTINEL) {
-            const unsigned long long key = *mybest;
-            if ((uint32_t)key != 0xffffffffu) {
-                const uint32_t sf = L.dsf[threadIdx.x];
-                const float t = (sf & 2u) ? -0.0f : __uint_as_float((uint32_t)(key >> 32));
-                hit[slot] = make_float4(t, L.du[threadIdx.x], L.dv[threadIdx.x], __int_as_float((int)(uint32_t)key - lmesh->tri_base));
-                side_out[slot] = (uint8_t)(sf & 1u);
-            }
-            have = false;
-        }
-        if (!LOCAL && have && !need_setup && ref == SENTINEL) {
-            const unsigned long long key = *mybest;
-            if ((uint32_t)key != 0xffffffffu) {
-                const float t = __uint_as_float((uint32_t)(key >> 32));
-                // replaces the scene-level nearest iff t < h.t, or t == h.t and this instance comes EARLIER in the
-                // reference's visiting order than the holder of h.t (scene.rs:196,251 keep the earlier node on equal t)
-                const bool tie_ok = (uint32_t)inst_idx < (hinst & 0x7fffffffu);
-                if (t < ht || (tie_ok && t == ht)) {
-                    // the record in hit[] is brought up to date right away: only t and the instance stay in registers
-                    const uint32_t sf = L.dsf[threadIdx.x];
-                    ht = (sf & 2u) ? -0.0f : t;
-                    hinst = (uint32_t)inst_idx | ((sf & 1u) << 31);
-                    hit[slot] = make_float4(ht, L.du[threadIdx.x], L.dv[threadIdx.x], __int_as_float((int)(uint32_t)key));
-                    hit_inst[slot] = hinst;
-                }
-            }
-            ++mpos;
-            need_setup = true;
-        }
+#ifdef HPT_DEBUG_SLOTS
+        if (COUNT && HPT_DEBUG_SLOTS == 6) n_inst++;      // rounds of the outer loop (x 64)
+        if (COUNT && HPT_DEBUG_SLOTS == 8 && need_setup) n_inst++;   // lanes set up
+#endif
         // ---- setup: next mesh instance whose root box the ray enters, or retire the ray
         if (LOCAL && need_setup) {
             lo = xyz(ray_o[slot]); ld = xyz(ray_d[slot]);
@@ -640,10 +670,31 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             bound_s = HPT_INF; *mybest = HPT_KEY_NONE;
             stk.put(0, SENTINEL); sp = 1; ref = lmesh->root_ref;
         }
-        if (!LOCAL && need_setup) {
-            const f3 o = xyz(FAT ? ((const float4*)mq)[mq_n + item_at] : ray_o[slot]), d = xyz(FAT ? ((const float4*)mq)[2u * mq_n + item_at] : ray_d[slot]);
+        // FAT: the first mesh instance of a ray needs no chain, no instance record and no root-box test (the analytic stage did all
+        // three and left the mesh-local ray in the slot); its DMesh is read through scalar loads, one round per distinct mesh
+        // among the lanes (one round in a one-mesh scene)
+        const bool fast = FAT && !LOCAL && fresh;
+        if (fast) {
+            lo = xyz(((const float4*)mq)[mq_n + item_at]); ld = xyz(((const float4*)mq)[2u * mq_n + item_at]);
+            inst_idx = sc.mesh_instances[mpos];      // (needed at the merge only: the load has the whole walk to arrive)
+            rb = make_raybox(lo, ld);
+            bool todo = true;
+            for (unsigned long long left; (left = __ballot(todo)) != 0ull;) {
+                const int m0 = __builtin_amdgcn_readlane(first_mesh, (int)__builtin_ctzll(left));      // wave-uniform: the record comes through scalar loads
+                const DMesh mesh = load_uniform(sc.meshes, m0);
+                if (todo && first_mesh == m0) {
+                    if (NODE32) rb = quant_slab(rb, mesh.qbase, mesh.qscale);
+                    ref = mesh.root_ref;
+                    todo = false;
+                }
+            }
+            bound_s = ht * HPT_SLACK; *mybest = HPT_KEY_NONE;
+            stk.put(0, SENTINEL); sp = 1;
+        }
+        if (!LOCAL && ((need_setup && !fast) || next_mesh)) {
+            const f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);      // the world ray: only rays that go on to a further mesh instance get here
             for (;;) {
-                if (mpos >= sc.n_mesh_instances) { have = false; ref = SENTINEL; break; }      // hit[slot] is final
+                if (mpos >= sc.n_mesh_instances) { have = false; ref = SENTINEL; break; }
                 inst_idx = sc.mesh_instances[mpos];
                 const DInstance* in = sc.instances + inst_idx;
                 lo = o; ld = d;
@@ -673,6 +724,7 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             int cl = 0, cr = 0;      // child refs that are leaves whose box the ray enters (negative), else 0
 #ifdef HPT_DEBUG_SLOTS      // tuning builds: lane slots of the inner loop are added to the instance-test counter
             if (COUNT && (HPT_DEBUG_SLOTS == 1 || (HPT_DEBUG_SLOTS == 2 && exhausted) || (HPT_DEBUG_SLOTS == 3 && !have))) n_inst++;
+            if (COUNT && HPT_DEBUG_SLOTS == 7 && ref != SENTINEL) n_inst++;      // lanes that hold a node or a leaf in this step
 #endif
             if (ref >= 0) {
                 if (COUNT) n_int++;
@@ -695,23 +747,49 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
             const unsigned long long mL = __ballot(cl < 0), mR = __ballot(cr < 0);
             if (mL | mR) {
                 bool tested = false;
+#if HPT_PEND_FIFO
+                if (cl < 0) { const uint32_t q = qtail + lane_prefix(mL); const unsigned e = lbase + (q & (uint32_t)(HPT_LEAF_CAP - 1)); L.ltri[e] = (uint32_t)~cl; L.lown[e] = (uint8_t)lane; my_last = q + 1u; }
+                qtail += (uint32_t)__popcll(mL);
+                if (qtail - qhead >= 64u) { test_pending<COUNT, true>(L, tris, qhead, 64u, lo, ld, n_tri); qhead += 64u; tested = true; }
+                if (cr < 0) { const uint32_t q = qtail + lane_prefix(mR); const unsigned e = lbase + (q & (uint32_t)(HPT_LEAF_CAP - 1)); L.ltri[e] = (uint32_t)~cr; L.lown[e] = (uint8_t)lane; my_last = q + 1u; }
+                qtail += (uint32_t)__popcll(mR);
+                if (qtail - qhead >= 64u) { test_pending<COUNT, true>(L, tris, qhead, 64u, lo, ld, n_tri); qhead += 64u; tested = true; }
+#else
                 if (cl < 0) { const unsigned e = lbase + pend + lane_prefix(mL); L.ltri[e] = (uint32_t)~cl; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mL);
                 if (pend >= 64u) { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); tested = true; }
                 if (cr < 0) { const unsigned e = lbase + pend + lane_prefix(mR); L.ltri[e] = (uint32_t)~cr; L.lown[e] = (uint8_t)lane; }
                 pend += (unsigned)__popcll(mR);
                 if (pend >= 64u) { pend -= 64u; test_pending<COUNT>(L, tris, pend, 64u, lo, ld, n_tri); tested = true; }
+#endif
                 if (tested) bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
             }
         }
+#if HPT_PEND_FIFO
+        // ---- entries stay pending across refills.  A lane whose mesh is finished waits until its own entries have been tested (in the
+        //      full batches of the loop above); only when fewer than HPT_PEND_FIFO lanes could be refilled -- or nothing is left to
+        //      pull -- the list is emptied as a partial batch.
+        if (__ballot(have && ref == SENTINEL && !HPT_FLUSHED) != 0ull) {
+            const int ready = __popcll(__ballot(!have || (ref == SENTINEL && HPT_FLUSHED)));
+            if (exhausted || ready < HPT_PEND_FIFO) {
+                while (qhead != qtail) {
+                    const unsigned n = qtail - qhead < 64u ? qtail - qhead : 64u;
+                    test_pending<COUNT, true>(L, tris, qhead, n, lo, ld, n_tri);
+                    qhead += n;
+                }
+            }
+        }
+#else
         // ---- what is still pending is tested before any lane merges or changes its ray
         while (pend) {
             const unsigned n = pend < 64u ? pend : 64u;
             pend -= n;
             test_pending<COUNT>(L, tris, pend, n, lo, ld, n_tri);
         }
+#endif
         bound_s = fminf(__uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32)), ht) * HPT_SLACK;
     }
+#undef HPT_FLUSHED
 }
 
 // ------------------------------------------------------------------------------------------------ two-level traversal
