@@ -12,8 +12,10 @@
  *  - plain pointers and sizes only.  The library copies every input array during the call (caller keeps ownership).
  *  - matrices are 3x3 COLUMN-major float[9] (m[c*3+r]) like cgmath::Matrix3 (scene.rs:102-105 Transform).
  *  - one hpt_context drives ONE GPU from one host thread.  Several GPUs: either one process per GPU, each with its own
- *    context rendering a sample range (first_sample, spp) of every pixel, summed afterwards (bench.py: torch.distributed
- *    over RCCL), or ONE process and an hpt_group (below), which does the split and the RCCL reduce itself.
+ *    context adding a sample range (first_sample, spp) of every pixel to an accumulator (hpt_render_accum_device), the
+ *    accumulators summed afterwards (bench.py: torch.distributed over RCCL, int64 sum), or ONE process and an hpt_group
+ *    (below), which does the split and the RCCL reduce itself.  The accumulator is integer (hpt_accum): the image does
+ *    not depend, in any bit, on how many GPUs rendered it.
  *  - destroy scenes before their context (a context destroyed earlier is kept alive until its last scene goes).
  *  - a context is not thread-safe.  All work of a context is ordered on one HIP stream (its own, or the one
  *    given to hpt_context_set_stream): it starts behind what that stream holds and is complete when that stream
@@ -117,6 +119,20 @@ typedef struct {
     double seconds_total;      /* incl. H2D/D2H copies for the host-pointer entry */
 } hpt_trace_stats;
 
+/* The radiance accumulator of one pixel: main.rs:67,109 collect a pixel's samples and add them up (f32, in sample order).
+ * Here the sums are 64-bit FIXED-POINT numbers -- sample * 2^HPT_ACCUM_FRAC_BITS rounded to nearest, |sample| clamped to
+ * HPT_ACCUM_SAMPLE_MAX first (+-inf included); a sample with a NaN channel adds 0 to that channel and 1 to `nan` -- because
+ * integer addition is associative: the accumulator holds the same bits whatever the pass size, the number of GPUs the
+ * samples were split over, the order in which RCCL adds the ranks, or the points at which a render was stopped and resumed.
+ * The rounding error is <= 2^-25 per sample (the reference's own f32 fold is coarser); sums stay below 2^63 for up to
+ * 2^18 samples per pixel even if every one of them is at the clamp.  hpt_accum_resolve turns it into the image. */
+#define HPT_ACCUM_FRAC_BITS 24
+#define HPT_ACCUM_SAMPLE_MAX 1048576.0f
+typedef struct {
+    int64_t r, g, b;           /* fixed-point sums of the samples' radiance */
+    int64_t nan;               /* samples that had a NaN channel: the pixel resolves to NaN, as the reference's f32 sum would */
+} hpt_accum;
+
 typedef struct {               /* what hpt_scene_commit laid out in HBM */
     int32_t n_instances, n_mesh_instances, n_meshes, n_materials;
     int32_t n_nodes;           /* Node64 records, all BLASes + the TLAS */
@@ -202,33 +218,47 @@ int hpt_scene_intersect(hpt_scene* scene, int64_t n, const float* org3, const fl
 int hpt_render(hpt_scene* scene, const hpt_render_params* params, float* rgb, uint32_t* samples_per_px,
                hpt_render_stats* stats);
 /* fixed-spp only, DEVICE output: rgb_sum (W*H*3 floats, device memory) receives the per-pixel SUM over this
- * call's sample range (no division) so that ranks can be summed (RCCL) and divided once.  Synchronises the
- * context stream before returning only if stats != NULL. */
+ * call's sample range (no division), i.e. the accumulator's sums rounded to f32.  Synchronises the context stream
+ * before returning only if stats != NULL.  (To combine several calls -- ranks, rounds, a resumed render -- without a
+ * dependence on the split, add into ONE accumulator with hpt_render_accum_device instead of adding these floats.) */
 int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
                       hpt_render_stats* stats);
-/* hpt_render_device for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc.  No counterpart in the reference (its main.rs:55 allocates the frame buffer per run).  Same
- * arguments, same kernels and bit-identical output as hpt_render_device, but the pass buffers (wavefront queues, hit and
- * radiance records, counters, Halton table) come from a static device array of HPT_NOALLOC_SCRATCH_MB (98) MB that each
- * GPU the library runs on holds until the process ends, instead of from hipMalloc: the call allocates nothing (no
- * hipMalloc / hipFree, no stream or event creation).  Limits (HPT_ERR_LIMIT beyond them): the frame has at most
- * HPT_NOALLOC_MAX_PIXELS = 2^19 pixels (the reference's 800 x 600 fits) and a call renders at most HPT_NOALLOC_MAX_SPP =
- * 4096 samples (continue with first_sample).  Fixed-spp only; HPT_RENDER_TIME_KERNELS is refused (it creates events).
- * One pass at a time on the context stream.  Every call on a GPU shares that GPU's one array (whatever the context or
- * scene): calls that overlap on one GPU race -- serialise them. */
+/* hpt_render_device for callers that cannot allocate -- tight serving loops, harnesses that forbid hipMalloc.  No
+ * counterpart in the reference (its main.rs:55 allocates the frame buffer per run).  Same arguments, same kernels and
+ * bit-identical output as hpt_render_device, but the pass buffers (wavefront queues, hit and radiance records, counters,
+ * Halton table, the call's accumulator) come from a static device array of HPT_NOALLOC_SCRATCH_MB MB that each GPU the
+ * library runs on holds until the process ends, instead of from hipMalloc: the call allocates nothing (no hipMalloc /
+ * hipFree, no stream or event creation, no host allocation) and copies nothing from the host; with stats == NULL it does
+ * not synchronise either -- it enqueues kernels and memsets on the context stream and returns (stats != NULL: one
+ * synchronisation at the end, to read the counters).  It has not been tried under HIP graph capture.  Limits
+ * (HPT_ERR_LIMIT beyond them): the frame has at most HPT_NOALLOC_MAX_PIXELS = 2^19 pixels (the reference's 800 x 600
+ * fits) and a call renders at most HPT_NOALLOC_MAX_SPP = 4096 samples (continue with first_sample).  Fixed-spp only;
+ * HPT_RENDER_TIME_KERNELS is refused (it creates events).  One pass at a time on the context stream.  Every call on a
+ * GPU shares that GPU's one array (whatever the context or scene): calls that overlap on one GPU race -- serialise them. */
 #define HPT_NOALLOC_MAX_PIXELS (1u << 19)
 #define HPT_NOALLOC_MAX_SPP 4096
-#define HPT_NOALLOC_SCRATCH_MB 98
+#define HPT_NOALLOC_SCRATCH_MB 124
 int hpt_render_device_noalloc(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
                               hpt_render_stats* stats);
-/* One round of the adaptive loop (main.rs:72-99 restricted to a sample range) on DEVICE buffers, for hosts that
- * drive the rounds themselves -- a rank of a multi-GPU adaptive render renders its share of the round's samples and
- * all-reduces the min/max planes before the contrast test.  params: adaptive = 0, first_sample, spp =
- * this call's sample range; pixel_list (device, n_pixels entries; NULL = every pixel in order) = the pixels still
- * active.  rgb_sum (W*H*3) is ADDED to; minmax (W*H*6: per pixel min r,g,b then max r,g,b; the caller initialises
- * min = +inf, max = 0 as main.rs:90-92) is folded into; NULL skips it. */
-int hpt_render_round_device(hpt_scene* scene, const hpt_render_params* params, const uint32_t* pixel_list_device,
-                            uint32_t n_pixels, float* rgb_sum_device, float* minmax_device, hpt_render_stats* stats);
+/* Samples first_sample+1 ..= first_sample+spp (params: adaptive = 0) of the listed pixels ADDED to a caller-held
+ * accumulator on the DEVICE (W*H records, zeroed by the caller before the first call): main.rs:72-99 restricted to a
+ * sample range.  The building block of every render made of several calls -- a rank of a multi-GPU render adds its share
+ * of the samples and the ranks' accumulators are summed (int64: ncclInt64 / torch.int64); a host that drives the
+ * adaptive rounds itself (min/max planes all-reduced between rounds); a progressive or resumed render -- and
+ * none of these splits changes a bit of the result.  pixel_list (device, n_pixels entries; NULL = every pixel in order)
+ * = the pixels still active; minmax (W*H*6: per pixel min r,g,b then max r,g,b; the caller initialises min = +inf,
+ * max = 0 as main.rs:90-92) is folded into; NULL skips it.  Synchronises only if stats != NULL. */
+int hpt_render_accum_device(hpt_scene* scene, const hpt_render_params* params, const uint32_t* pixel_list_device,
+                            uint32_t n_pixels, hpt_accum* accum_device, float* minmax_device, hpt_render_stats* stats);
+/* The same for every pixel with the accumulator in HOST memory (copied in, added to, copied out): resumable rendering for
+ * hosts that hold no device memory -- a checkpoint is this array + the sample cursor (host/main.cpp --checkpoint). */
+int hpt_render_accum(hpt_scene* scene, const hpt_render_params* params, hpt_accum* accum, hpt_render_stats* stats);
+/* accumulator -> image, main.rs:109-110 (`total / num_samples as f32`): rgb = f32(sum) / n with n = samples_per_px[pixel]
+ * if given, else num_samples; num_samples == 0 without samples_per_px: no division (the sums).  Device form (context
+ * stream, no synchronisation; W*H pixels of the scene's camera) and host form: the same IEEE operations, the same bits. */
+int hpt_accum_resolve_device(hpt_scene* scene, const hpt_accum* accum_device, const uint32_t* samples_per_px_device,
+                             uint32_t num_samples, float* rgb_device);
+int hpt_accum_resolve(const hpt_accum* accum, uint32_t n_pixels, const uint32_t* samples_per_px, uint32_t num_samples, float* rgb);
 /* The contrast test of main.rs:101-106 on DEVICE buffers: list_out receives those pixels of list_in (NULL = all)
  * with (max-min)/(min+max) above a threshold in any channel, their samples_per_px entry is set to next_num_samples,
  * *n_out (host) = how many.  The order of list_out is unspecified (results do not depend on it).  Synchronises. */
@@ -244,9 +274,9 @@ int hpt_render_samples(hpt_scene* scene, const hpt_render_params* params, float*
  * twice or HPT_GROUP_TRANSPORT=p2p is set, an RCCL communicator over them (ncclCommInitAll; librccl.so.1 is loaded at
  * this call).  The host builds and commits ONE scene on hpt_group_context(group, 0); hpt_group_render replicates it on
  * the other GPUs (again whenever it was re-committed), renders a contiguous share of the samples of every pixel on each
- * GPU from a host thread of its own, sum-reduces the float accumulators onto GPU 0 (ncclReduce over xGMI; transport p2p:
- * peer copies + adds in rank order) and returns sum / num_samples on the host like hpt_render.  The RNG is keyed by
- * (pixel, sample), so the set of paths does not depend on the number of GPUs; only the grouping of the float sums does.
+ * GPU from a host thread of its own, sum-reduces the accumulators onto GPU 0 (ncclReduce of int64 over xGMI; transport
+ * p2p: peer copies + adds) and returns sum / num_samples on the host like hpt_render.  The RNG is keyed by (pixel,
+ * sample) and the accumulators are integer (hpt_accum): the image is the one-GPU image, bit for bit, for any GPU count.
  * Adaptive mode runs the rounds of main.rs:67-107 in lock step: min/max planes all-reduced per round, identical active
  * sets on every GPU, per-pixel sample counts identical to the one-GPU render.
  * Destroy the scene before the group.  Not thread-safe; one host thread drives a group. */

@@ -3,6 +3,7 @@
 // matrix inverses below are computed in the reference's f32 operation order.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -99,7 +100,8 @@ struct hpt_scene {
     hpt_texture background, environment;
     hpt_camera camera;
     bool have_camera = false, committed = false;
-    uint64_t generation = 0;    // commits so far (a group re-replicates a scene that was committed again)
+    uint64_t generation = 0;    // stamp of the last commit, unique in the process (a group re-replicates its clones when the stamp of
+                                // the scene it is handed differs -- a re-commit, or ANOTHER scene that the allocator put at the same address)
     // device side
     DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_meshinst, d_xinv, d_xfwd, d_materials, d_images, d_pool;
     std::vector<DMesh> h_meshes;
@@ -211,7 +213,8 @@ static int context_init(hpt_context* c) {
     for (hipEvent_t& e : c->ev_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->stream = c->own_stream;
     // this device's address of the static workspace of the no-alloc entry point (once per device, with it current)
-    CHK(hptk_scratch(device, &c->scratch, &c->scratch_bytes));
+    // (a failure leaves it null: only hpt_render_device_noalloc needs it, and reports HPT_ERR_STATE then)
+    if (hptk_scratch(device, &c->scratch, &c->scratch_bytes) != 0) { c->scratch = nullptr; c->scratch_bytes = 0; }
     return HPT_OK;
 }
 // Scenes keep a pointer to their context (device, streams): destroying the context first would leave them dangling
@@ -668,7 +671,8 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     if (const char* e = getenv("HPT_SHADE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) s->shade_grid = ctx->num_cus * v; }
     s->analytic_grid = s->plan.analytic_per_cu > 0 ? ctx->num_cus * s->plan.analytic_per_cu * 2 : ctx->max_blocks;      // (4 / 8 / 16 per CU with two passes in flight: 13.47 / 13.62 / 14.05 Grays/s)
     if (const char* e = getenv("HPT_ANALYTIC_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) s->analytic_grid = ctx->num_cus * v; }
-    s->committed = true; s->generation++;
+    static std::atomic<uint64_t> commit_stamp{0};
+    s->committed = true; s->generation = ++commit_stamp;
     return HPT_OK;
 }
 
@@ -860,10 +864,10 @@ static int extend_grid(const hpt_scene* s, int inflight) {
     return ctx->num_cus * std::max(1, per_cu);
 }
 
-// `st`: the stream of this pass; `after` (may be null): the resolve of the previous pass, on the other stream -- sums
-// go into `accum` in sample order, so the resolves of consecutive passes are chained; `done` (may be null) is recorded
-// behind this pass's resolve.
-static int run_pass(hpt_scene* s, DPass& ps, float* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks,
+// `st`: the stream of this pass; `after` (may be null): the resolve of the previous pass, on the other stream -- the
+// resolves of consecutive passes read and write the same accumulator, so they are chained (the sums themselves do not
+// depend on the order: 64-bit fixed point); `done` (may be null) is recorded behind this pass's resolve.
+static int run_pass(hpt_scene* s, DPass& ps, long long* accum, float* minmax, bool counters, EventLog& ev, int extend_blocks,
                     hipStream_t st, hipEvent_t after, hipEvent_t done) {
     hpt_context* ctx = s->ctx;
     HIPCHK(hipMemsetAsync(ps.counts, 0, (size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t), st));
@@ -930,9 +934,9 @@ static int check_params(hpt_scene* s, const hpt_render_params* p) {
 }
 
 // Render of samples first_sample+1 ..= first_sample+spp of the n_active pixels in pixel_list (device; NULL = every
-// pixel, n_active = W*H) into accum (device, W*H*3, ADDED in sample order) and, when minmax != NULL, folded into the
+// pixel, n_active = W*H) into accum (device, W*H hpt_accum records, ADDED to) and, when minmax != NULL, folded into the
 // per-channel running min/max of main.rs:90-100.
-static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t* pixel_list, uint32_t n_active, float* accum, float* minmax,
+static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t* pixel_list, uint32_t n_active, long long* accum, float* minmax,
                         float* per_sample_host, hpt_render_stats* stats, EventLog& ev) {
     hpt_context* ctx = s->ctx;
     hipStream_t st = ctx->stream;
@@ -955,10 +959,8 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
     CHK(ensure_pass_workspace(s, npix * (uint64_t)S, psv[0], 0));
     for (int k = 1; k < inflight; ++k)
         if (ensure_pass_workspace(s, npix * (uint64_t)S, psv[k], k) != HPT_OK) { inflight = k; (void)hipGetLastError(); break; }   // no memory for another set of pass buffers: fewer in flight
-    std::vector<float> hal((size_t)p->spp * 2);
-    for (int k = 0; k < p->spp; ++k) { hal[2 * k] = hpt_halton(p->first_sample + k + 1, 2); hal[2 * k + 1] = hpt_halton(p->first_sample + k + 1, 3); }
-    CHK(upload(s->w_halton, hal, st));
-    HIPCHK(hipStreamSynchronize(st));   // `hal` is pageable host memory
+    CHK(s->w_halton.ensure((size_t)p->spp * sizeof(float2)));
+    hptk_halton(st, s->w_halton.as<float2>(), (uint32_t)p->first_sample, (uint32_t)p->spp);      // scene.rs:431 on the device: no copy, no synchronisation
     std::vector<float> rad;
     uint32_t passes = 0;
     if (inflight > 1) {
@@ -1000,7 +1002,7 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
     return HPT_OK;
 }
 
-static int render_fixed(hpt_scene* s, const hpt_render_params* p, float* accum, float* per_sample_host, hpt_render_stats* stats, EventLog& ev) {
+static int render_fixed(hpt_scene* s, const hpt_render_params* p, long long* accum, float* per_sample_host, hpt_render_stats* stats, EventLog& ev) {
     return render_range(s, p, nullptr, (uint32_t)((uint64_t)s->ds.cam.w * s->ds.cam.h), accum, nullptr, per_sample_host, stats, ev);
 }
 
@@ -1028,21 +1030,24 @@ extern "C" int hpt_render_device(hpt_scene* s, const hpt_render_params* p, float
     const double t0 = now_s();
     if (stats) std::memset(stats, 0, sizeof *stats);
     const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
-    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
+    CHK(s->w_stat.ensure(8 * sizeof(unsigned long long))); CHK(s->w_accum.ensure(npix * sizeof(hpt_accum)));
     HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    HIPCHK(hipMemsetAsync(rgb_sum_device, 0, npix * 3 * sizeof(float), ctx->stream));
+    HIPCHK(hipMemsetAsync(s->w_accum.p, 0, npix * sizeof(hpt_accum), ctx->stream));
     EventLog ev{ctx, stats && (p->flags & HPT_RENDER_TIME_KERNELS)};
-    CHK(render_fixed(s, p, rgb_sum_device, nullptr, stats, ev));
+    CHK(render_fixed(s, p, s->w_accum.as<long long>(), nullptr, stats, ev));
+    hptk_accum_resolve(ctx->stream, ctx->max_blocks, s->w_accum.as<long long>(), nullptr, rgb_sum_device, (uint32_t)npix, 0.0f);      // the sums as f32
+    HIPCHK(hipGetLastError());
     return finish_stats(s, stats, ev, t0);
 }
 
-// hpt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
-// forbid hipMalloc): the pass buffers -- wavefront queues, hit and radiance records, append counters, statistics, Halton
-// table -- are carved from this device's copy of the static `scratch` array of hpt_kernels.hip (ctx->scratch, resolved
-// once per device by hipGetSymbolAddress in hpt_context_create) instead of the scene's grow-only hipMalloc workspace.
-// One pass at a time on the context stream; calls no hipMalloc / hipFree / event or stream creation, and no host
-// allocation either (the Halton table is built on the stack).  Same kernels, same pass order, same sums as
-// hpt_render_device -> bit-identical output.  Every call on a GPU uses that GPU's one array: overlapping calls race.
+// hpt_render_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc): the pass
+// buffers -- wavefront queues, hit and radiance records, append counters, statistics, Halton table, the call's radiance
+// accumulator -- are carved from this device's copy of the static `scratch` array of hpt_kernels.hip (ctx->scratch,
+// resolved once per device by hipGetSymbolAddress in hpt_context_create) instead of the scene's grow-only hipMalloc
+// workspace.  One pass at a time on the context stream; calls no hipMalloc / hipFree / event or stream creation, no host
+// allocation, no host-to-device copy, and -- with stats == NULL -- no synchronisation: it only enqueues kernels and
+// memsets (the Halton table is filled by a kernel).  Same kernels and the same fixed-point sums as hpt_render_device ->
+// bit-identical output.  Every call on a GPU uses that GPU's one array: overlapping calls race.
 extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* p, float* rgb_sum_device, hpt_render_stats* stats) {
     CHK(check_params(s, p));
     if (p->adaptive) return fail(HPT_ERR_INVALID, "hpt_render_device_noalloc: fixed-spp only");
@@ -1071,10 +1076,11 @@ extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* 
     ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.mq = (uint4*)(base + HPT_NOALLOC_OFF_MQ); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
     ps.stat = (unsigned long long*)(base + HPT_NOALLOC_OFF_STAT);
     float2* d_halton = (float2*)(base + HPT_NOALLOC_OFF_HALTON);
-    // the array keeps the last call's contents: statistics start at zero here, counters and radiance per pass (run_pass)
+    long long* d_accum = (long long*)(base + HPT_NOALLOC_OFF_ACCUM);
+    // the array keeps the last call's contents: statistics and the accumulator start at zero here, counters and radiance per pass (run_pass)
     HIPCHK(hipMemsetAsync(ps.stat, 0, 8 * sizeof(unsigned long long), st));
-    HIPCHK(hipMemsetAsync(rgb_sum_device, 0, npix * 3 * sizeof(float), st));
-    float hal[2 * 64];      // Halton values of one pass's samples, staged on the stack
+    HIPCHK(hipMemsetAsync(d_accum, 0, npix * sizeof(hpt_accum), st));
+    hptk_halton(st, d_halton, (uint32_t)p->first_sample, (uint32_t)p->spp);      // the whole call's samples (<= HPT_NOALLOC_MAX_SPP), once
     // as many samples of every pixel per pass as the workspace holds (hpt_render_device: 64 M paths per pass)
     int S = (int)std::min<uint64_t>(std::min<uint64_t>(HPT_NOALLOC_MAX_PATHS / npix, 64), (uint64_t)p->spp);
     if (p->spp_per_pass > 0) S = std::min(S, p->spp_per_pass);
@@ -1082,17 +1088,16 @@ extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* 
     uint32_t passes = 0;
     for (int done = 0; done < p->spp; done += S) {
         const int cur = std::min(S, p->spp - done);
-        for (int k = 0; k < cur; ++k) { hal[2 * k] = hpt_halton(p->first_sample + done + k + 1, 2); hal[2 * k + 1] = hpt_halton(p->first_sample + done + k + 1, 3); }
-        HIPCHK(hipMemcpyAsync(d_halton + done, hal, (size_t)cur * sizeof(float2), hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));      // `hal` is reused by the next pass (pageable host memory)
         ps.halton = d_halton + done;
         ps.pixel_list = nullptr; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
         ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
         ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
         if ((uint64_t)ps.shard_cap * HPT_SHARDS > HPT_NOALLOC_SLOTS) return fail(HPT_ERR_LIMIT, "hpt_render_device_noalloc: pass of %llu paths does not fit the static workspace", (unsigned long long)(npix * (uint64_t)cur));
-        CHK(run_pass(s, ps, rgb_sum_device, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s, 1), st, nullptr, nullptr));
+        CHK(run_pass(s, ps, d_accum, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s, 1), st, nullptr, nullptr));
         ++passes;
     }
+    hptk_accum_resolve(st, ctx->max_blocks, d_accum, nullptr, rgb_sum_device, (uint32_t)npix, 0.0f);
+    HIPCHK(hipGetLastError());
     if (stats) { stats->passes = passes; stats->samples = npix * (uint64_t)p->spp; }
     return finish_stats(s, stats, ev, t0, ps.stat);
 }
@@ -1103,12 +1108,12 @@ extern "C" int hpt_render_samples(hpt_scene* s, const hpt_render_params* p, floa
     hpt_context* ctx = s->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
-    CHK(s->w_accum.ensure(npix * 3 * sizeof(float)));
+    CHK(s->w_accum.ensure(npix * sizeof(hpt_accum)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    HIPCHK(hipMemsetAsync(s->w_accum.p, 0, npix * 3 * sizeof(float), ctx->stream));
+    HIPCHK(hipMemsetAsync(s->w_accum.p, 0, npix * sizeof(hpt_accum), ctx->stream));
     EventLog ev{ctx, false};
-    CHK(render_fixed(s, p, s->w_accum.as<float>(), per_sample, nullptr, ev));
+    CHK(render_fixed(s, p, s->w_accum.as<long long>(), per_sample, nullptr, ev));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return HPT_OK;
 }
@@ -1122,15 +1127,15 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
     const double t0 = now_s();
     if (stats) std::memset(stats, 0, sizeof *stats);
     const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
-    CHK(s->w_accum.ensure(npix * 3 * sizeof(float))); CHK(s->w_out.ensure(npix * 3 * sizeof(float)));
+    CHK(s->w_accum.ensure(npix * sizeof(hpt_accum))); CHK(s->w_out.ensure(npix * 3 * sizeof(float)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), st));
-    HIPCHK(hipMemsetAsync(s->w_accum.p, 0, npix * 3 * sizeof(float), st));
-    float* accum = s->w_accum.as<float>();
+    HIPCHK(hipMemsetAsync(s->w_accum.p, 0, npix * sizeof(hpt_accum), st));
+    long long* accum = s->w_accum.as<long long>();
     EventLog ev{ctx, stats && (p->flags & HPT_RENDER_TIME_KERNELS)};
     if (!p->adaptive) {
         CHK(render_fixed(s, p, accum, nullptr, stats, ev));
-        hptk_divide(st, ctx->max_blocks, accum, nullptr, s->w_out.as<float>(), (uint32_t)npix, (float)p->spp);
+        hptk_accum_resolve(st, ctx->max_blocks, accum, nullptr, s->w_out.as<float>(), (uint32_t)npix, (float)p->spp);
         if (samples_per_px) for (uint64_t i = 0; i < npix; ++i) samples_per_px[i] = (uint32_t)p->spp;
     } else {
         // main.rs:67-107 in wavefront form: rounds of samples (have, num_samples] over the still-active pixels
@@ -1158,7 +1163,7 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
             cur_list = next;
             num_samples *= 2;
         }
-        hptk_divide(st, ctx->max_blocks, accum, s->w_spp.as<uint32_t>(), s->w_out.as<float>(), (uint32_t)npix, 0.0f);
+        hptk_accum_resolve(st, ctx->max_blocks, accum, s->w_spp.as<uint32_t>(), s->w_out.as<float>(), (uint32_t)npix, 0.0f);
         HIPCHK(hipStreamSynchronize(st));
         if (samples_per_px) HIPCHK(hipMemcpy(samples_per_px, s->w_spp.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
@@ -1169,16 +1174,18 @@ extern "C" int hpt_render(hpt_scene* s, const hpt_render_params* p, float* rgb, 
     return HPT_OK;
 }
 
-// One round of the adaptive loop with DEVICE buffers, for hosts that drive the rounds themselves (one rank of a
-// multi-GPU adaptive render: the min/max planes are all-reduced between rounds, hpt/dist.py).
-extern "C" int hpt_render_round_device(hpt_scene* s, const hpt_render_params* p, const uint32_t* pixel_list_device, uint32_t n_pixels,
-                                       float* rgb_sum_device, float* minmax_device, hpt_render_stats* stats) {
+// Samples first_sample+1 ..= first_sample+spp of the listed pixels ADDED to a caller-held accumulator on the DEVICE: the
+// building block of everything that renders a frame in several calls -- a rank of a multi-GPU render (its share of the
+// samples; the accumulators of the ranks are then summed, ncclInt64), one round of the adaptive loop driven by the host
+// (hpt/dist.py, hpt_group.cpp), a progressive or resumed render.  The sums are integers: the split changes no bit.
+extern "C" int hpt_render_accum_device(hpt_scene* s, const hpt_render_params* p, const uint32_t* pixel_list_device, uint32_t n_pixels,
+                                       hpt_accum* accum_device, float* minmax_device, hpt_render_stats* stats) {
     CHK(check_params(s, p));
-    if (p->adaptive) return fail(HPT_ERR_INVALID, "hpt_render_round_device: params describe ONE round (adaptive = 0, first_sample, spp)");
-    if (!rgb_sum_device) return fail(HPT_ERR_INVALID, "hpt_render_round_device: null accumulator");
+    if (p->adaptive) return fail(HPT_ERR_INVALID, "hpt_render_accum_device: params describe ONE sample range (adaptive = 0, first_sample, spp)");
+    if (!accum_device) return fail(HPT_ERR_INVALID, "hpt_render_accum_device: null accumulator");
     const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
     if (!pixel_list_device) n_pixels = (uint32_t)npix;
-    if (n_pixels > npix) return fail(HPT_ERR_INVALID, "hpt_render_round_device: %u listed pixels, image has %llu", n_pixels, (unsigned long long)npix);
+    if (n_pixels > npix) return fail(HPT_ERR_INVALID, "hpt_render_accum_device: %u listed pixels, image has %llu", n_pixels, (unsigned long long)npix);
     hpt_context* ctx = s->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     const double t0 = now_s();
@@ -1186,9 +1193,52 @@ extern "C" int hpt_render_round_device(hpt_scene* s, const hpt_render_params* p,
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(s->w_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     EventLog ev{ctx, stats && (p->flags & HPT_RENDER_TIME_KERNELS)};
-    CHK(render_range(s, p, pixel_list_device, n_pixels, rgb_sum_device, minmax_device, nullptr, stats, ev));
+    CHK(render_range(s, p, pixel_list_device, n_pixels, (long long*)accum_device, minmax_device, nullptr, stats, ev));
     if (stats) { stats->samples = (uint64_t)n_pixels * (uint64_t)p->spp; }
     return finish_stats(s, stats, ev, t0);
+}
+
+// The same with the accumulator in HOST memory (uploaded, added to, downloaded): resumable rendering for a host that holds
+// no device memory of its own -- the command-line programs (host/main.cpp --checkpoint / --resume, rust/main_render.rs).
+extern "C" int hpt_render_accum(hpt_scene* s, const hpt_render_params* p, hpt_accum* accum, hpt_render_stats* stats) {
+    CHK(check_params(s, p));
+    if (p->adaptive) return fail(HPT_ERR_INVALID, "hpt_render_accum: fixed sample range only (adaptive = 0, first_sample, spp)");
+    if (!accum) return fail(HPT_ERR_INVALID, "hpt_render_accum: null accumulator");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t npix = (uint64_t)s->ds.cam.w * s->ds.cam.h;
+    CHK(s->w_accum.ensure(npix * sizeof(hpt_accum)));
+    HIPCHK(hipMemcpyAsync(s->w_accum.p, accum, npix * sizeof(hpt_accum), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // (pageable host memory)
+    CHK(hpt_render_accum_device(s, p, nullptr, 0, s->w_accum.as<hpt_accum>(), nullptr, stats));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(accum, s->w_accum.p, npix * sizeof(hpt_accum), hipMemcpyDeviceToHost));
+    return HPT_OK;
+}
+
+// accumulator -> image (main.rs:109-110: total / num_samples as f32), device and host form of the same arithmetic
+extern "C" int hpt_accum_resolve_device(hpt_scene* s, const hpt_accum* accum_device, const uint32_t* samples_per_px_device, uint32_t num_samples, float* rgb_device) {
+    CHK(need_committed(s));
+    if (!accum_device || !rgb_device) return fail(HPT_ERR_INVALID, "hpt_accum_resolve_device: null pointer");
+    hpt_context* ctx = s->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hptk_accum_resolve(ctx->stream, ctx->max_blocks, (const long long*)accum_device, samples_per_px_device, rgb_device, (uint32_t)((uint64_t)s->ds.cam.w * s->ds.cam.h), (float)num_samples);
+    HIPCHK(hipGetLastError());
+    return HPT_OK;
+}
+extern "C" int hpt_accum_resolve(const hpt_accum* accum, uint32_t n_pixels, const uint32_t* samples_per_px, uint32_t num_samples, float* rgb) {
+    if (!accum || !rgb) return fail(HPT_ERR_INVALID, "hpt_accum_resolve: null pointer");
+    for (uint32_t i = 0; i < n_pixels; ++i) {
+        const hpt_accum& a = accum[i];
+        const float n = samples_per_px ? (float)samples_per_px[i] : (float)num_samples;
+        float v[3] = {(float)((double)a.r * (1.0 / HPT_ACCUM_SCALE_D)), (float)((double)a.g * (1.0 / HPT_ACCUM_SCALE_D)), (float)((double)a.b * (1.0 / HPT_ACCUM_SCALE_D))};
+        for (int c = 0; c < 3; ++c) {
+            if (a.nan != 0) v[c] = std::nanf("");
+            if (samples_per_px || num_samples != 0) v[c] = v[c] / n;
+            rgb[3 * (size_t)i + c] = v[c];
+        }
+    }
+    return HPT_OK;
 }
 
 // main.rs:101-106 on DEVICE buffers: which of the listed pixels go on to the next round.

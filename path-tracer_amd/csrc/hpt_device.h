@@ -45,6 +45,11 @@
 #define HPT_PIECE_BATCH 8
 #endif
 
+// ---- the radiance accumulator (include/hpt.h hpt_accum): 4 x int64 per pixel, sums in fixed point ----
+#define HPT_ACCUM_SCALE_F 16777216.0f          // 2^HPT_ACCUM_FRAC_BITS
+#define HPT_ACCUM_SCALE_D 16777216.0
+#define HPT_ACCUM_SAMPLE_MAX_F 1048576.0f      // HPT_ACCUM_SAMPLE_MAX
+
 // ---- static workspace of hpt_render_device_noalloc (hpt_kernels.hip `scratch`) ----
 #define HPT_NOALLOC_MAX_PATHS (1u << 19)   // pixels of the largest frame it renders (one sample of every pixel per pass; the reference's 800 x 600 fits)
 #ifndef HPT_NOALLOC_MAX_SPP
@@ -53,7 +58,8 @@
 // queue slots: 64 segments, each rounded up to whole 256-path chunks
 #define HPT_NOALLOC_SLOTS ((size_t)HPT_NOALLOC_MAX_PATHS + (size_t)HPT_SHARDS * HPT_BLOCK)
 #define HPT_ALIGN256(x) (((size_t)(x) + 255) & ~(size_t)255)
-// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), mesh queue (3 x 16 B), counters, statistics, Halton
+// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), mesh queue (3 x 16 B), counters, statistics, Halton,
+// the radiance accumulator of the call (32 B per pixel)
 #define HPT_NOALLOC_OFF_Q(k) ((size_t)(k) * HPT_ALIGN256(HPT_NOALLOC_SLOTS * 16))
 #define HPT_NOALLOC_OFF_HIT HPT_NOALLOC_OFF_Q(6)
 #define HPT_NOALLOC_OFF_RADIANCE HPT_NOALLOC_OFF_Q(7)
@@ -62,7 +68,8 @@
 #define HPT_NOALLOC_OFF_COUNTS (HPT_NOALLOC_OFF_MQ + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 48))
 #define HPT_NOALLOC_OFF_STAT (HPT_NOALLOC_OFF_COUNTS + HPT_ALIGN256((size_t)HPT_COUNTS_TOTAL * 4))
 #define HPT_NOALLOC_OFF_HALTON (HPT_NOALLOC_OFF_STAT + 256)
-#define HPT_NOALLOC_SCRATCH_BYTES (HPT_NOALLOC_OFF_HALTON + HPT_ALIGN256((size_t)HPT_NOALLOC_MAX_SPP * 8))
+#define HPT_NOALLOC_OFF_ACCUM (HPT_NOALLOC_OFF_HALTON + HPT_ALIGN256((size_t)HPT_NOALLOC_MAX_SPP * 8))
+#define HPT_NOALLOC_SCRATCH_BYTES (HPT_NOALLOC_OFF_ACCUM + HPT_ALIGN256((size_t)HPT_NOALLOC_MAX_PATHS * 32))
 
 struct DMesh {
     int32_t root_ref;     // ref of the root (interior index or ~tri for a one-triangle mesh)

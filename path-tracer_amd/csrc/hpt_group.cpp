@@ -4,9 +4,11 @@
 // Here the machine is up to 8 MI355X: a group holds one context per GPU, the committed scene is REPLICATED on each
 // (SURVEY 8e), every GPU renders a contiguous range of the samples of every pixel on a host thread of its own -- the
 // counter-based RNG is keyed by (pixel, sample), so the set of paths does not depend on the number of GPUs -- and the one
-// exchange step is a sum-reduce of the float accumulators onto GPU 0: RCCL (`ncclReduce`, communicator from
+// exchange step is a sum-reduce of the accumulators onto GPU 0: RCCL (`ncclReduce` of int64, communicator from
 // `ncclCommInitAll`, over xGMI), or -- transport "p2p", chosen automatically when a device appears twice in the list,
-// which RCCL refuses -- peer copies onto GPU 0 followed by adds in rank order (bitwise independent of timing).
+// which RCCL refuses -- peer copies onto GPU 0 followed by adds.  The accumulators are 64-bit fixed point (include/hpt.h
+// hpt_accum): integer sums do not depend on the order RCCL adds the ranks in, nor on how the samples were split, so the image
+// is the one-GPU image bit for bit.
 // Adaptive mode (main.rs:67-107) runs the rounds in lock step: each GPU renders its share of the round's samples, the
 // per-channel min/max planes are combined with one all-reduce (max over [-min, max]), and every GPU then runs the
 // contrast test on identical data and keeps an identical active set.
@@ -203,14 +205,14 @@ static int ensure_replicas(hpt_group* g, hpt_scene* scene) {
 }
 static hpt_scene* scene_of(hpt_group* g, hpt_scene* scene, int r) { return r == 0 ? scene : g->ranks[r].replica; }
 
-// sum of the ranks' float accumulators onto rank 0 (n floats each); every rank's stream is drained on return
+// sum of the ranks' accumulators onto rank 0 (n int64 each); every rank's stream is drained on return
 static int reduce_sum(hpt_group* g, size_t n) {
     const int world = (int)g->ranks.size();
     if (g->rccl) {
         GNCCL(g_rccl.GroupStart());
         for (int r = 0; r < world; ++r) {
             Rank& k = g->ranks[r];
-            const ncclResult_t e = g_rccl.Reduce(k.accum.p, k.accum.p, n, ncclFloat, ncclSum, 0, k.comm, hpti_context_stream(k.ctx));
+            const ncclResult_t e = g_rccl.Reduce(k.accum.p, k.accum.p, n, ncclInt64, ncclSum, 0, k.comm, hpti_context_stream(k.ctx));
             if (e != ncclSuccess) { (void)g_rccl.GroupEnd(); return hpti_fail(HPT_ERR_DEVICE, "ncclReduce failed: %s", g_rccl.GetErrorString(e)); }
         }
         GNCCL(g_rccl.GroupEnd());
@@ -221,12 +223,12 @@ static int reduce_sum(hpt_group* g, size_t n) {
     Rank& root = g->ranks[0];
     GHIP(hipSetDevice(root.device));
     hipStream_t st = hpti_context_stream(root.ctx);
-    if (world > 1) GCHK(root.stage.ensure(root.device, n * sizeof(float)));
-    for (int r = 1; r < world; ++r) {      // rank order: the result does not depend on which GPU finished first
+    if (world > 1) GCHK(root.stage.ensure(root.device, n * sizeof(long long)));
+    for (int r = 1; r < world; ++r) {
         Rank& k = g->ranks[r];
-        if (k.device == root.device) GHIP(hipMemcpyAsync(root.stage.p, k.accum.p, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        else GHIP(hipMemcpyPeerAsync(root.stage.p, root.device, k.accum.p, k.device, n * sizeof(float), st));
-        hptk_add_f32(st, hpti_context_max_blocks(root.ctx), (float*)root.accum.p, (const float*)root.stage.p, n);
+        if (k.device == root.device) GHIP(hipMemcpyAsync(root.stage.p, k.accum.p, n * sizeof(long long), hipMemcpyDeviceToDevice, st));
+        else GHIP(hipMemcpyPeerAsync(root.stage.p, root.device, k.accum.p, k.device, n * sizeof(long long), st));
+        hptk_add_i64(st, hpti_context_max_blocks(root.ctx), (long long*)root.accum.p, (const long long*)root.stage.p, n);
         GHIP(hipGetLastError());
     }
     GHIP(hipStreamSynchronize(st));
@@ -294,7 +296,7 @@ extern "C" int hpt_group_render(hpt_group* g, hpt_scene* scene, const hpt_render
     if (stats) { std::memset(stats, 0, sizeof *stats); stats->n_devices = world; stats->transport = g->rccl ? 0 : 1; }
     std::vector<hpt_render_stats> rst((size_t)world);
     std::vector<double> busy((size_t)world, 0.0);
-    for (Rank& k : g->ranks) GCHK(k.accum.ensure(k.device, npix * 3 * sizeof(float)));
+    for (Rank& k : g->ranks) GCHK(k.accum.ensure(k.device, npix * sizeof(hpt_accum)));
     double reduce_s = 0.0;
     Rank& root = g->ranks[0];
     hipStream_t st0 = hpti_context_stream(root.ctx);
@@ -304,22 +306,22 @@ extern "C" int hpt_group_render(hpt_group* g, hpt_scene* scene, const hpt_render
             Rank& k = g->ranks[r];
             int lo, n; sample_range(r, world, p->spp, &lo, &n);
             const double t = now_s();
+            GHIP(hipMemsetAsync(k.accum.p, 0, npix * sizeof(hpt_accum), hpti_context_stream(k.ctx)));
             if (n == 0) {
-                GHIP(hipMemsetAsync(k.accum.p, 0, npix * 3 * sizeof(float), hpti_context_stream(k.ctx)));
                 GHIP(hipStreamSynchronize(hpti_context_stream(k.ctx)));
                 return HPT_OK;
             }
             hpt_render_params q = *p; q.first_sample = p->first_sample + lo; q.spp = n;
-            const int rc = hpt_render_device(scene_of(g, scene, r), &q, (float*)k.accum.p, &rst[r]);      // (stats given: synchronises)
+            const int rc = hpt_render_accum_device(scene_of(g, scene, r), &q, nullptr, 0, (hpt_accum*)k.accum.p, nullptr, &rst[r]);      // (stats given: synchronises)
             busy[r] = now_s() - t;
             return rc;
         }));
         const double tr = now_s();
-        GCHK(reduce_sum(g, npix * 3));
+        GCHK(reduce_sum(g, npix * 4));
         reduce_s += now_s() - tr;
         GHIP(hipSetDevice(root.device));
         GCHK(root.stage.ensure(root.device, npix * 3 * sizeof(float)));
-        hptk_divide(st0, hpti_context_max_blocks(root.ctx), (const float*)root.accum.p, nullptr, (float*)root.stage.p, (uint32_t)npix, (float)p->spp);      // main.rs:110
+        hptk_accum_resolve(st0, hpti_context_max_blocks(root.ctx), (const long long*)root.accum.p, nullptr, (float*)root.stage.p, (uint32_t)npix, (float)p->spp);      // main.rs:110
         GHIP(hipGetLastError());
         GHIP(hipStreamSynchronize(st0));
         GHIP(hipMemcpy(rgb, root.stage.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -333,7 +335,7 @@ extern "C" int hpt_group_render(hpt_group* g, hpt_scene* scene, const hpt_render
         GCHK(per_rank(g, [&](int r) -> int {
             Rank& k = g->ranks[r];
             hipStream_t st = hpti_context_stream(k.ctx);
-            GHIP(hipMemsetAsync(k.accum.p, 0, npix * 3 * sizeof(float), st));
+            GHIP(hipMemsetAsync(k.accum.p, 0, npix * sizeof(hpt_accum), st));
             hptk_init_minmax(st, hpti_context_max_blocks(k.ctx), (float*)k.minmax.p, (uint32_t)npix);                       // main.rs:90-92
             hptk_fill_u32(st, hpti_context_max_blocks(k.ctx), (uint32_t*)k.spp.p, npix, (uint32_t)p->initial_samples);
             GHIP(hipGetLastError());
@@ -350,8 +352,8 @@ extern "C" int hpt_group_render(hpt_group* g, hpt_scene* scene, const hpt_render
                 const double t = now_s();
                 hpt_render_params q = *p; q.adaptive = 0; q.first_sample = have + lo; q.spp = n;
                 hpt_render_stats one;
-                const int rc = hpt_render_round_device(scene_of(g, scene, r), &q, cur < 0 ? nullptr : (const uint32_t*)k.list[cur].p, n_active,
-                                                       (float*)k.accum.p, (float*)k.minmax.p, &one);
+                const int rc = hpt_render_accum_device(scene_of(g, scene, r), &q, cur < 0 ? nullptr : (const uint32_t*)k.list[cur].p, n_active,
+                                                       (hpt_accum*)k.accum.p, (float*)k.minmax.p, &one);
                 busy[r] += now_s() - t;
                 rst[r].rays_primary += one.rays_primary; rst[r].rays_bounce += one.rays_bounce; rst[r].samples += one.samples; rst[r].passes += one.passes;
                 return rc;
@@ -373,11 +375,11 @@ extern "C" int hpt_group_render(hpt_group* g, hpt_scene* scene, const hpt_render
             n_active = n_out[0]; cur = next; num *= 2;
         }
         const double tr = now_s();
-        GCHK(reduce_sum(g, npix * 3));
+        GCHK(reduce_sum(g, npix * 4));
         reduce_s += now_s() - tr;
         GHIP(hipSetDevice(root.device));
         GCHK(root.stage.ensure(root.device, npix * 3 * sizeof(float)));
-        hptk_divide(st0, hpti_context_max_blocks(root.ctx), (const float*)root.accum.p, (const uint32_t*)root.spp.p, (float*)root.stage.p, (uint32_t)npix, 0.0f);
+        hptk_accum_resolve(st0, hpti_context_max_blocks(root.ctx), (const long long*)root.accum.p, (const uint32_t*)root.spp.p, (float*)root.stage.p, (uint32_t)npix, 0.0f);
         GHIP(hipGetLastError());
         GHIP(hipStreamSynchronize(st0));
         GHIP(hipMemcpy(rgb, root.stage.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));

@@ -21,13 +21,14 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
 void hptk_extend_analytic(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, bool count);
 void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, bool count);
 void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat);
-void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, float* accum, float* minmax);
+void hptk_halton(hipStream_t st, float2* out, uint32_t first_sample, uint32_t n);      // out[k] = halton(first_sample + k + 1, 2 | 3)
+void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, long long* accum, float* minmax);
 void hptk_finish_pass(hipStream_t st, const DPass& ps);
 void hptk_adaptive_select(hipStream_t st, int max_blocks, const uint32_t* in_list, uint32_t n_in, const float* minmax, const float thr[3],
                           uint32_t* out_list, uint32_t* out_count, uint32_t* samples_per_px, uint32_t num_samples_next);
 void hptk_fill_f32(hipStream_t st, int max_blocks, float* p, size_t n, float v);
 // group render (hpt_group.cpp): partial results of the ranks combined on one device
-void hptk_add_f32(hipStream_t st, int max_blocks, float* dst, const float* src, size_t n);
+void hptk_add_i64(hipStream_t st, int max_blocks, long long* dst, const long long* src, size_t n);
 void hptk_minmax_merge(hipStream_t st, int max_blocks, float* dst, const float* src, size_t n);
 void hptk_negate_min(hipStream_t st, int max_blocks, float* p, size_t n);
 void hptk_init_minmax(hipStream_t st, int max_blocks, float* p, uint32_t npix);      // main.rs:90-92
@@ -35,5 +36,5 @@ void hptk_init_minmax(hipStream_t st, int max_blocks, float* p, uint32_t npix); 
 // device must be current).  0 on success.
 int hptk_scratch(int device, void** out, size_t* bytes);
 void hptk_fill_u32(hipStream_t st, int max_blocks, uint32_t* p, size_t n, uint32_t v);
-void hptk_divide(hipStream_t st, int max_blocks, const float* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n);
+void hptk_accum_resolve(hipStream_t st, int max_blocks, const long long* accum, const uint32_t* samples, float* out, uint32_t npix, float fixed_n);
 void hptk_set_refill(int lanes);   // tuning: idle lanes per wave that trigger a refill in drain_queue

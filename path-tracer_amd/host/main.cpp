@@ -24,6 +24,9 @@ static void usage() {
         "  --gpus N           one call over the first N GPUs (0 = all): hpt_group_render -- samples split over the GPUs, RCCL\n"
         "                     sum-reduce onto GPU 0 (also: HPT_GPUS=N in the environment, as rust/main_render.rs reads it)\n"
         "  --library-bvh      let the library build its SAH tree instead of handing over the bvh.rs tree\n"
+        "  --checkpoint FILE  (with --spp N) keep the accumulator + sample cursor of this render in FILE\n"
+        "  --resume FILE      (with --spp M) continue the render of FILE with M more samples per pixel; the image is the one a\n"
+        "                     single run of all the samples writes, byte for byte (integer accumulator)\n"
         "  --stats            print ray counts and timings to stderr\n"
         "  --dump-scene FILE  write the loaded scene (exact float bits + digests) and exit; needs no GPU\n");
 }
@@ -32,7 +35,7 @@ int main(int argc, char** argv) {
     try {
         std::vector<std::string> pos;
         int spp = 0, depth = 8, device = 0; unsigned seed = 1; bool library_bvh = false, stats = false;
-        int ow = 0, oh = 0; std::string dump;
+        int ow = 0, oh = 0; std::string dump, checkpoint, resume;
         int gpus = -1;      // -1: one context on --device; >= 0: a group
         if (const char* e = std::getenv("HPT_GPUS")) gpus = std::atoi(e);
         for (int i = 1; i < argc; ++i) {
@@ -46,6 +49,8 @@ int main(int argc, char** argv) {
             else if (a == "--size") { if (std::sscanf(val(), "%dx%d", &ow, &oh) != 2 || ow <= 0 || oh <= 0) throw Error("--size wants WxH"); }
             else if (a == "--library-bvh") library_bvh = true;
             else if (a == "--stats") stats = true;
+            else if (a == "--checkpoint") checkpoint = val();
+            else if (a == "--resume") resume = val();
             else if (a == "--dump-scene") dump = val();
             else if (a == "-h" || a == "--help") { usage(); return 0; }
             else pos.push_back(a);
@@ -59,6 +64,9 @@ int main(int argc, char** argv) {
         }
         if (pos.size() < 2) { usage(); throw Error("please provide a scene description file and an image output file"); }   // main.rs:36-38
 
+        const bool accumulate = !checkpoint.empty() || !resume.empty();
+        if (accumulate && spp <= 0) throw Error("--checkpoint / --resume need --spp N (a fixed number of samples per pixel for this run)");
+        if (accumulate && gpus >= 0) throw Error("--checkpoint / --resume drive one GPU (--device); not available with --gpus");
         SceneDesc d = load_scene(pos[0], !library_bvh);
         if (ow) { d.camera.img_width = (uint32_t)ow; d.camera.img_height = (uint32_t)oh; }
 
@@ -88,6 +96,35 @@ int main(int argc, char** argv) {
             if (hpt_group_render(group, scene, &p, rgb.data(), counts.data(), &gs) != HPT_OK) throw Error(std::string("hpt_group_render: ") + hpt_last_error());
             st.rays_primary = gs.rays_primary; st.rays_bounce = gs.rays_bounce; st.samples = gs.samples; st.seconds_total = gs.seconds_total;
             if (stats) std::fprintf(stderr, "%d GPU(s), %s: slowest render %.3f s, exchange steps %.4f s\n", gs.n_devices, gs.transport ? "peer copies" : "RCCL", gs.seconds_render_max, gs.seconds_reduce);
+        } else if (accumulate) {
+            // Resumable render: the checkpoint is the accumulator (hpt_accum per pixel: 64-bit fixed-point sums) + the sample
+            // cursor + what the samples depend on (frame size, seed, depth cap).  Samples are keyed by (pixel, index) and the
+            // sums are integers, so N samples now + M after a restart leave the bits one run of N + M leaves.
+            struct Header { char magic[8]; uint32_t width, height, seed; int32_t depth; int64_t cursor; };
+            std::vector<hpt_accum> acc(npix);
+            std::memset(acc.data(), 0, npix * sizeof(hpt_accum));
+            int64_t cursor = 0;
+            if (!resume.empty()) {
+                std::ifstream f(resume, std::ios::binary);
+                Header h;
+                if (!f || !f.read((char*)&h, sizeof h) || std::memcmp(h.magic, "HPTACC1", 8) != 0) throw Error("cannot read checkpoint " + resume);
+                if (h.width != d.camera.img_width || h.height != d.camera.img_height || h.seed != seed || h.depth != depth)
+                    throw Error("checkpoint " + resume + " was rendered with another frame size, seed or depth");
+                if (!f.read((char*)acc.data(), (std::streamsize)(npix * sizeof(hpt_accum)))) throw Error("checkpoint " + resume + " is truncated");
+                cursor = h.cursor;
+            }
+            p.adaptive = 0; p.first_sample = (int32_t)cursor; p.spp = spp;
+            if (hpt_render_accum(scene, &p, acc.data(), &st) != HPT_OK) throw Error(std::string("hpt_render_accum: ") + hpt_last_error());
+            cursor += spp;
+            if (hpt_accum_resolve(acc.data(), (uint32_t)npix, nullptr, (uint32_t)cursor, rgb.data()) != HPT_OK) throw Error(std::string("hpt_accum_resolve: ") + hpt_last_error());
+            if (!checkpoint.empty()) {
+                Header h; std::memset(&h, 0, sizeof h);
+                std::memcpy(h.magic, "HPTACC1", 8);
+                h.width = d.camera.img_width; h.height = d.camera.img_height; h.seed = seed; h.depth = depth; h.cursor = cursor;
+                std::ofstream f(checkpoint, std::ios::binary);
+                if (!f || !f.write((const char*)&h, sizeof h) || !f.write((const char*)acc.data(), (std::streamsize)(npix * sizeof(hpt_accum)))) throw Error("cannot write checkpoint " + checkpoint);
+            }
+            if (stats) std::fprintf(stderr, "samples %lld..%lld of every pixel\n", (long long)(cursor - spp + 1), (long long)cursor);
         } else if (hpt_render(scene, &p, rgb.data(), counts.data(), &st) != HPT_OK) throw Error(std::string("hpt_render: ") + hpt_last_error());
         std::vector<uint8_t> rgba(npix * 4);
         if (hpt_tonemap_rgba8(rgb.data(), (uint32_t)npix, rgba.data()) != HPT_OK) throw Error(std::string("hpt_tonemap_rgba8: ") + hpt_last_error());

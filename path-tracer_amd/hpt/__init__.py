@@ -54,6 +54,15 @@ class RenderStats(C.Structure):
                 ("seconds_analytic", C.c_double), ("rays_mesh", C.c_uint64)]
 
 
+class Accum(C.Structure):
+    """hpt_accum: the radiance accumulator of one pixel (64-bit fixed point, 2^-24 quantum) -- as numpy / torch: int64 [npix, 4]"""
+    _fields_ = [("r", C.c_int64), ("g", C.c_int64), ("b", C.c_int64), ("nan", C.c_int64)]
+
+
+ACCUM_FRAC_BITS = 24
+ACCUM_SAMPLE_MAX = 1048576.0
+
+
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("seconds_kernel", C.c_double), ("seconds_total", C.c_double)]
@@ -78,7 +87,8 @@ EXPORTS = [
     "hpt_scene_create", "hpt_scene_destroy", "hpt_scene_add_mesh", "hpt_scene_add_image", "hpt_scene_add_material",
     "hpt_scene_add_node", "hpt_scene_set_background", "hpt_scene_set_environment", "hpt_scene_set_camera", "hpt_scene_commit",
     "hpt_trace_rays", "hpt_trace_rays_device", "hpt_scene_intersect", "hpt_render", "hpt_render_device", "hpt_render_samples",
-    "hpt_scene_info", "hpt_render_round_device", "hpt_adaptive_select_device", "hpt_render_device_noalloc",
+    "hpt_scene_info", "hpt_render_accum_device", "hpt_render_accum", "hpt_accum_resolve_device", "hpt_accum_resolve",
+    "hpt_adaptive_select_device", "hpt_render_device_noalloc",
     "hpt_group_create", "hpt_group_destroy", "hpt_group_size", "hpt_group_context", "hpt_group_render",
 ]
 
@@ -154,7 +164,10 @@ def _load():
     lib.hpt_group_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderParams), F32P, U32P, C.POINTER(GroupStats)]
     lib.hpt_render_samples.argtypes = [C.c_void_p, C.POINTER(RenderParams), F32P]
     lib.hpt_scene_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
-    lib.hpt_render_round_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
+    lib.hpt_render_accum_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(RenderStats)]
+    lib.hpt_render_accum.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
+    lib.hpt_accum_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.hpt_accum_resolve.argtypes = [C.c_void_p, C.c_uint32, U32P, C.c_uint32, F32P]
     lib.hpt_adaptive_select_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, F32P, C.c_void_p, C.c_void_p, C.c_uint32, U32P]
     return lib
 
@@ -398,13 +411,25 @@ class Scene:
         check(lib.hpt_scene_info(self.h, C.byref(out)))
         return out
 
-    def render_round_device(self, accum_ptr, minmax_ptr, pixel_list_ptr, n_pixels, want_stats=False, **kw):
-        """one adaptive round on device buffers (hpt_render_round_device); pixel_list_ptr = 0 for every pixel"""
+    def render_accum_device(self, accum_ptr, minmax_ptr, pixel_list_ptr, n_pixels, want_stats=False, **kw):
+        """a sample range added to a device accumulator (hpt_render_accum_device: int64 [npix, 4]); pixel_list_ptr = 0 for every pixel"""
         p = self.params(**kw)
         st = RenderStats()
-        check(lib.hpt_render_round_device(self.h, C.byref(p), C.c_void_p(pixel_list_ptr or None), n_pixels, C.c_void_p(accum_ptr),
+        check(lib.hpt_render_accum_device(self.h, C.byref(p), C.c_void_p(pixel_list_ptr or None), n_pixels, C.c_void_p(accum_ptr),
                                           C.c_void_p(minmax_ptr or None), C.byref(st) if want_stats else None))
         return st
+
+    def render_accum(self, accum, want_stats=False, **kw):
+        """hpt_render_accum: a sample range added to a HOST accumulator (numpy int64 [npix, 4], modified in place)"""
+        assert accum.dtype == np.int64 and accum.flags["C_CONTIGUOUS"] and accum.size == self.width * self.height * 4
+        p = self.params(**kw)
+        st = RenderStats()
+        check(lib.hpt_render_accum(self.h, C.byref(p), accum.ctypes.data_as(C.c_void_p), C.byref(st) if want_stats else None))
+        return st
+
+    def accum_resolve_device(self, accum_ptr, out_ptr, num_samples=0, spp_ptr=0):
+        """hpt_accum_resolve_device: out (float32 [npix, 3], device) = f32(sum) / n; n = spp[pixel] | num_samples | no division"""
+        check(lib.hpt_accum_resolve_device(self.h, C.c_void_p(accum_ptr), C.c_void_p(spp_ptr or None), int(num_samples), C.c_void_p(out_ptr)))
 
     def adaptive_select_device(self, list_in_ptr, n_in, minmax_ptr, thresholds, list_out_ptr, spp_ptr, next_num_samples):
         thr = (C.c_float * 3)(*[float(t) for t in thresholds])
@@ -426,6 +451,15 @@ class Scene:
 
     def __del__(self):
         self.close()
+
+
+def accum_resolve(accum, num_samples=0, samples_per_px=None):
+    """hpt_accum_resolve on the host: int64 [npix, 4] -> float32 [npix, 3]"""
+    accum = np.ascontiguousarray(accum, dtype=np.int64).reshape(-1, 4)
+    out = np.empty((len(accum), 3), dtype=np.float32)
+    spp = np.ascontiguousarray(samples_per_px, dtype=np.uint32).reshape(-1) if samples_per_px is not None else None
+    check(lib.hpt_accum_resolve(accum.ctypes.data_as(C.c_void_p), len(accum), _p(spp, U32P), int(num_samples), _p(out, F32P)))
+    return out
 
 
 def tonemap_rgba8(rgb):

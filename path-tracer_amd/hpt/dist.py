@@ -1,7 +1,8 @@
 """Multi-GPU partition of the render path: every (pixel, sample) path is independent (main.rs:57,72 are pure
 maps), so rank r of W renders the sample range [lo, hi) of EVERY pixel -- the counter-based RNG is keyed by
 (pixel, sample index), hence the set of paths does not depend on W -- and the one exchange step is a sum-reduce of
-the float accumulators (RCCL over xGMI with backend "nccl"; gloo in the CPU tests)."""
+the accumulators (RCCL over xGMI with backend "nccl"; gloo in the CPU tests).  The accumulators are 64-bit fixed point
+(include/hpt.h hpt_accum; here: int64 tensors [npix, 4]): the reduced image does not depend on W in any bit."""
 
 
 def sample_range(rank, world, spp):
@@ -45,7 +46,7 @@ def allreduce_minmax(minmax):
 
 
 class DeviceRounds:
-    """The adaptive rounds of one rank on its GPU (hpt_render_round_device / hpt_adaptive_select_device) behind the small
+    """The adaptive rounds of one rank on its GPU (hpt_render_accum_device / hpt_adaptive_select_device) behind the small
     interface render_adaptive() drives: new_buffers, render_round, select.  Work is enqueued on torch's current stream
     (the context is pointed at it) so that the collectives between rounds are ordered after the kernels."""
 
@@ -66,7 +67,7 @@ class DeviceRounds:
 
     def new_buffers(self, initial_samples):
         t = self.torch
-        accum = t.zeros(self.npix * 3, dtype=t.float32, device="cuda")
+        accum = t.zeros((self.npix, 4), dtype=t.int64, device="cuda")      # hpt_accum records
         minmax = t.empty((self.npix, 6), dtype=t.float32, device="cuda")
         minmax[:, :3] = float("inf"); minmax[:, 3:] = 0.0          # main.rs:90-92
         spp = t.full((self.npix,), int(initial_samples), dtype=t.int32, device="cuda")
@@ -74,9 +75,15 @@ class DeviceRounds:
 
     def render_round(self, first_sample, count, n_active, accum, minmax):
         plist = 0 if self.cur < 0 else self.lists[self.cur].data_ptr()
-        st = self.scene.render_round_device(accum.data_ptr(), minmax.data_ptr(), plist, n_active, want_stats=True, spp=count,
+        st = self.scene.render_accum_device(accum.data_ptr(), minmax.data_ptr(), plist, n_active, want_stats=True, spp=count,
                                             first_sample=first_sample, max_depth=self.max_depth, seed=self.seed, spp_per_pass=self.spp_per_pass)
         self.rays += st.rays_primary + st.rays_bounce
+
+    def resolve(self, accum, spp):
+        """main.rs:110 with the per-pixel sample counts: float32 [npix, 3] on the device"""
+        out = self.torch.empty((self.npix, 3), dtype=self.torch.float32, device="cuda")
+        self.scene.accum_resolve_device(accum.data_ptr(), out.data_ptr(), spp_ptr=spp.data_ptr())
+        return out
 
     def select(self, n_active, minmax, thresholds, spp, next_num_samples):
         nxt = 0 if self.cur < 0 else 1 - self.cur
@@ -89,7 +96,7 @@ class DeviceRounds:
 def render_adaptive(engine, rank=0, world=1, initial_samples=128, max_samples=512, thresholds=(0.4, 0.3, 0.6)):
     """main.rs:67-110 over `world` ranks: in every round (samples have+1..num of the still-active pixels) rank
     r renders its contiguous share of the round's samples; the min/max planes are all-reduced so that every rank runs
-    the contrast test on identical data and keeps an identical active set; the float sums are reduced once at the end.
+    the contrast test on identical data and keeps an identical active set; the (integer) sums are reduced once at the end.
     Returns (rgb [npix,3] on rank 0 else None, samples_per_px)."""
     accum, minmax, spp = engine.new_buffers(initial_samples)
     have, num, n_active = 0, int(initial_samples), engine.npix
@@ -106,4 +113,4 @@ def render_adaptive(engine, rank=0, world=1, initial_samples=128, max_samples=51
     reduce_sum(accum, dst=0)
     if rank != 0:
         return None, spp
-    return accum.view(-1, 3) / spp.view(-1, 1).to(accum.dtype), spp
+    return engine.resolve(accum, spp), spp

@@ -1,6 +1,6 @@
-"""Progressive / resumable accumulation: a checkpoint is the float accumulator plus the sample cursor.
-Samples are keyed by (pixel, sample index), so rendering samples [0, a) now and [a, b) after a restart gives the same
-sums as one call over [0, b) -- bit for bit, because every pixel's samples are added in index order either way."""
+"""Progressive / resumable accumulation: a checkpoint is the accumulator plus the sample cursor.
+Samples are keyed by (pixel, sample index) and the accumulator is integer (include/hpt.h hpt_accum), so rendering
+samples [0, a) now and [a, b) after a restart gives the same sums as one call over [0, b) -- bit for bit."""
 import numpy as np
 
 
@@ -15,12 +15,13 @@ class ProgressiveRender:
         self.stream = torch.cuda.Stream()
         scene.ctx.set_stream(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
-            self.accum = torch.zeros(self.npix * 3, dtype=torch.float32, device="cuda")
+            self.accum = torch.zeros((self.npix, 4), dtype=torch.int64, device="cuda")
+            self.out = torch.empty((self.npix, 3), dtype=torch.float32, device="cuda")
         self.cursor = 0          # samples per pixel accumulated so far
 
     def advance(self, spp):
         """adds samples cursor+1 ..= cursor+spp of every pixel"""
-        self.scene.render_round_device(self.accum.data_ptr(), 0, 0, self.npix, spp=spp, first_sample=self.cursor,
+        self.scene.render_accum_device(self.accum.data_ptr(), 0, 0, self.npix, spp=spp, first_sample=self.cursor,
                                        max_depth=self.max_depth, seed=self.seed, spp_per_pass=self.spp_per_pass)
         self.cursor += spp
         return self.cursor
@@ -30,7 +31,8 @@ class ProgressiveRender:
         if self.cursor == 0:
             raise ValueError("no samples yet")
         with self.torch.cuda.stream(self.stream):
-            img = (self.accum / float(self.cursor)).view(self.scene.height, self.scene.width, 3).cpu()
+            self.scene.accum_resolve_device(self.accum.data_ptr(), self.out.data_ptr(), num_samples=self.cursor)
+            img = self.out.view(self.scene.height, self.scene.width, 3).cpu()
         self.stream.synchronize()
         return img.numpy()
 

@@ -72,6 +72,10 @@ pub struct hpt_group_stats {
 }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+pub struct hpt_accum { pub r: i64, pub g: i64, pub b: i64, pub nan: i64 }   // 64-bit fixed point, 2^-24 quantum: integer sums do not depend on any split
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
 pub struct hpt_trace_stats { pub rays: u64, pub nodes_visited: u64, pub tris_tested: u64, pub seconds_kernel: f64, pub seconds_total: f64 }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
@@ -128,9 +132,17 @@ extern "C" {
     /// pixels and 4096 samples per call; calls that overlap on one GPU race.
     pub fn hpt_render_device_noalloc(scene: *mut hpt_scene, params: *const hpt_render_params, rgb_sum_device: *mut f32,
                                      stats: *mut hpt_render_stats) -> c_int;
-    pub fn hpt_render_round_device(scene: *mut hpt_scene, params: *const hpt_render_params, pixel_list_device: *const u32,
-                                   n_pixels: u32, rgb_sum_device: *mut f32, minmax_device: *mut f32,
+    /// A sample range added to a caller-held accumulator on the device (ranks, adaptive rounds, resumed renders).
+    pub fn hpt_render_accum_device(scene: *mut hpt_scene, params: *const hpt_render_params, pixel_list_device: *const u32,
+                                   n_pixels: u32, accum_device: *mut hpt_accum, minmax_device: *mut f32,
                                    stats: *mut hpt_render_stats) -> c_int;
+    /// The same for every pixel with the accumulator in host memory: a checkpoint is this array + the sample cursor.
+    pub fn hpt_render_accum(scene: *mut hpt_scene, params: *const hpt_render_params, accum: *mut hpt_accum,
+                            stats: *mut hpt_render_stats) -> c_int;
+    pub fn hpt_accum_resolve_device(scene: *mut hpt_scene, accum_device: *const hpt_accum, samples_per_px_device: *const u32,
+                                    num_samples: u32, rgb_device: *mut f32) -> c_int;
+    pub fn hpt_accum_resolve(accum: *const hpt_accum, n_pixels: u32, samples_per_px: *const u32, num_samples: u32,
+                             rgb: *mut f32) -> c_int;
     pub fn hpt_adaptive_select_device(scene: *mut hpt_scene, list_in_device: *const u32, n_in: u32, minmax_device: *const f32,
                                       thresholds: *const f32, list_out_device: *mut u32, samples_per_px_device: *mut u32,
                                       next_num_samples: u32, n_out: *mut u32) -> c_int;

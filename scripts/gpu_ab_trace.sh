@@ -11,7 +11,7 @@ cd /tmp
 for v in "$@"; do
   unset HPT_LIB_PATH HPT_EXTEND_BLOCKS_PER_CU
   if [ "$v" = "base4" ]; then export HPT_EXTEND_BLOCKS_PER_CU=4; elif [ "$v" != "base" ]; then export HPT_LIB_PATH=$REPO/path-tracer_amd/variants_$v.so; fi
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$v -o t -- python3 $REPO/bench.py --inflight 1 --spp 128 --steps 1 --warmup 1 --cpu-spp 0 --no-alt > $OUT/$v.json 2> $OUT/$v.err
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$v -o t -- python3 $REPO/bench.py --inflight 1 --spp 128 --steps 1 --warmup 1 --cpu-spp 0 --no-alt --no-others > $OUT/$v.json 2> $OUT/$v.err
   find $OUT/$v -name "*kernel_stats.csv" -exec cp {} $OUT/${v}_kernel_stats.csv \;
   rm -rf $OUT/$v
   echo "== $v"; head -3 $OUT/${v}_kernel_stats.csv

@@ -9,6 +9,6 @@ for spec in "$@"; do
   combos=("${next[@]}")
 done
 for c in "${combos[@]}"; do
-  out=$(env $c timeout -k 10 120 python bench.py --steps 1 --warmup 1 --spp ${SWEEP_SPP:-256} --cpu-spp 0 --no-alt 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+  out=$(env $c timeout -k 10 120 python bench.py --steps 1 --warmup 1 --spp ${SWEEP_SPP:-256} --cpu-spp 0 --no-alt --no-others 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
   echo "$c => $out"
 done

@@ -83,7 +83,7 @@ def test_rust_ffi_crate_declares_every_export():
     # struct sizes implied by the Rust field lists (all fields 4 or 8 bytes, natural alignment) == ctypes sizes
     sizes = {"hpt_bvh_node": hpt.BvhNode, "hpt_texture": hpt.Texture, "hpt_material": hpt.Material, "hpt_camera": hpt.Camera,
              "hpt_render_params": hpt.RenderParams, "hpt_render_stats": hpt.RenderStats, "hpt_trace_stats": hpt.TraceStats,
-             "hpt_scene_info_t": hpt.SceneInfo, "hpt_group_stats": hpt.GroupStats}
+             "hpt_scene_info_t": hpt.SceneInfo, "hpt_group_stats": hpt.GroupStats, "hpt_accum": hpt.Accum}
     prim = {"i32": 4, "u32": 4, "f32": 4, "i64": 8, "u64": 8, "f64": 8}
     import ctypes
     known = {}

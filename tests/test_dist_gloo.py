@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2 gloo.  Each rank renders its sample range of every pixel (here with the CPU oracle
-standing in for the device, as the checker), the accumulators are sum-reduced, and the result must equal the
-single-process render of all samples: the set of paths does not depend on the number of ranks."""
+standing in for the device, as the checker, and tests/accum_ref.py for the fixed-point accumulator), the accumulators are
+sum-reduced (int64), and the result must equal the single-process render of all samples BIT FOR BIT: the set of paths
+and the integer sums do not depend on the number of ranks."""
 import os
 import sys
 
@@ -37,24 +38,35 @@ def _worker(rank, world, port, spp, out_path):
     import oracle_lib as ol
     desc = resized(scene_io.load_scene(os.path.join(GOLDEN, "scene.xml")), 32, 24)
     sc = ol.OracleScene(ol.load(), desc)
+    import accum_ref
     lo, n = sample_range(rank, world, spp)
-    part = sc.render(spp=n, first_sample=lo, max_depth=4, seed=9, threads=2)["rgb"] * np.float32(n)   # per-rank SUM
-    acc = torch.from_numpy(part.copy())
+    npix = desc.camera.width * desc.camera.height
+    acc = np.zeros((npix, 4), dtype=np.int64)      # hpt_accum records
+    if n > 0:
+        accum_ref.accumulate(acc, sc.render(spp=n, first_sample=lo, max_depth=4, seed=9, threads=2, want_samples=True)["per_sample"])
+    acc = torch.from_numpy(acc)
     reduce_sum(acc, dst=0)
     if rank == 0:
-        np.save(out_path, acc.numpy() / np.float32(spp))
+        np.save(out_path, acc.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_render_matches_single(tmp_path, olib, desc):
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_render_matches_single(tmp_path, olib, desc, world):
+    import accum_ref
+    import hpt
     import oracle_lib as ol
-    spp, port = 8, 29000 + os.getpid() % 2000
-    out = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(2, port, spp, out), nprocs=2, join=True)
-    two = np.load(out)
-    one = ol.OracleScene(olib, resized(desc, 32, 24)).render(spp=spp, max_depth=4, seed=9)["rgb"]
-    np.testing.assert_allclose(two, one, rtol=2e-6, atol=1e-6)   # same paths; only the f32 summation grouping differs
+    spp, port = 8, 29000 + os.getpid() % 2000 + world
+    out = str(tmp_path / "acc.npy")
+    mp.spawn(_worker, args=(world, port, spp, out), nprocs=world, join=True)
+    ranks = np.load(out)
+    r = ol.OracleScene(olib, resized(desc, 32, 24)).render(spp=spp, max_depth=4, seed=9, want_samples=True)
+    one = accum_ref.accumulate(np.zeros((32 * 24, 4), dtype=np.int64), r["per_sample"])
+    np.testing.assert_array_equal(ranks, one)                      # integer sums: no dependence on the split
+    img = hpt.accum_resolve(ranks, num_samples=spp)                # the library's host-side resolve (no GPU needed) ...
+    np.testing.assert_array_equal(img, accum_ref.resolve(one, num_samples=spp))   # ... is the restated arithmetic
+    np.testing.assert_allclose(img.reshape(24, 32, 3), r["rgb"], rtol=2e-6, atol=1e-6)   # and the reference's f32 fold up to its own rounding
 
 
 class OracleRounds:
@@ -70,20 +82,21 @@ class OracleRounds:
     def new_buffers(self, initial_samples):
         mm = torch.empty((self.npix, 6), dtype=torch.float32)
         mm[:, :3] = float("inf"); mm[:, 3:] = 0.0
-        return torch.zeros(self.npix * 3, dtype=torch.float32), mm, torch.full((self.npix,), int(initial_samples), dtype=torch.int32)
+        return torch.zeros((self.npix, 4), dtype=torch.int64), mm, torch.full((self.npix,), int(initial_samples), dtype=torch.int32)
 
     def render_round(self, first_sample, count, n_active, accum, minmax):
         assert n_active == len(self.active)
         per = self.osc.render(spp=count, first_sample=first_sample, max_depth=self.max_depth, seed=self.seed, threads=2, want_samples=True)["per_sample"]
+        import accum_ref
+        accum_ref.accumulate(accum.numpy(), per[self.active], rows=self.active)      # in place (shared memory), as k_resolve
         per = torch.from_numpy(per[self.active])                       # [active, count, 3]
-        acc = accum.view(-1, 3)
         idx = torch.from_numpy(self.active)
-        part = acc[idx]
-        for k in range(count):                                         # sample order, as k_resolve
-            part = part + per[:, k]
-        acc[idx] = part
         minmax[idx, :3] = torch.minimum(minmax[idx, :3], per.min(dim=1).values)
         minmax[idx, 3:] = torch.maximum(minmax[idx, 3:], per.max(dim=1).values)
+
+    def resolve(self, accum, spp):
+        import accum_ref
+        return torch.from_numpy(accum_ref.resolve(accum.numpy(), samples_per_px=spp.numpy()))
 
     def select(self, n_active, minmax, thresholds, spp, next_num_samples):
         m = minmax[torch.from_numpy(self.active)].numpy()
@@ -120,6 +133,11 @@ def test_two_rank_adaptive_matches_single(tmp_path, olib, desc):
     mp.spawn(_adaptive_worker, args=(2, port, out), nprocs=2, join=True)
     two = np.load(out)
     one = ol.OracleScene(olib, resized(desc, 32, 24)).render(adaptive=True, initial=8, max_samples=32, max_depth=4, seed=9)
+    # the same protocol with ONE rank (no process group here: the collectives are no-ops): the integer sums make the
+    # two images equal bit for bit
+    from hpt.dist import render_adaptive
+    rgb1, spp1 = render_adaptive(OracleRounds(ol.OracleScene(olib, resized(desc, 32, 24)), 4, 9), 0, 1, initial_samples=8, max_samples=32)
+    np.testing.assert_array_equal(two["spp"], spp1.numpy()); np.testing.assert_array_equal(two["rgb"], rgb1.numpy())
     np.testing.assert_array_equal(two["spp"].reshape(24, 32), one["samples"])
     assert len(np.unique(one["samples"])) >= 2          # the test exercises more than one round
     np.testing.assert_allclose(two["rgb"].reshape(24, 32, 3), one["rgb"], rtol=3e-6, atol=1e-6)

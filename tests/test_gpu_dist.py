@@ -1,12 +1,12 @@
-"""The multi-GPU path of the PRODUCT on a GPU: sample-range split + sum-reduce of the float accumulators.
+"""The multi-GPU path of the PRODUCT on a GPU: sample-range split + sum-reduce of the accumulators.
 
 (a) one process per GPU, as bench.py runs under torch.distributed.run: two fresh child processes share GPU 0 (gloo
     rendezvous -- RCCL cannot put two ranks on one device), each with its own hpt.Context, rendering its sample_range
-    through hpt_render_device, and the adaptive rounds through hpt.dist.DeviceRounds / render_adaptive.
+    through hpt_render_accum_device, and the adaptive rounds through hpt.dist.DeviceRounds / render_adaptive.
 (b) one process, several GPUs: hpt_group_create / hpt_group_render behind the C ABI -- with RCCL (communicator of one: the
     1-GPU box has one device) and with the peer-copy transport over two and three ranks on GPU 0.
 Reference for both: the one-context render of all samples.  Same set of paths for any rank count (RNG keyed by pixel and
-sample); only the grouping of the f32 sums differs (<= few ulp); adaptive sample counts are identical."""
+sample) and integer sums (include/hpt.h hpt_accum): images and adaptive sample counts are IDENTICAL, bit for bit."""
 import os
 import sys
 
@@ -37,17 +37,19 @@ def _worker(rank, world, port, out_path):
         ctx.set_stream(stream.cuda_stream)
         # fixed spp: this rank's contiguous share of 11 samples (uneven split) of every pixel
         lo, n = sample_range(rank, world, 11)
-        accum = torch.zeros(W * H * 3, device="cuda")
-        st = sc.render_device(accum.data_ptr(), want_stats=True, spp=n, first_sample=lo, max_depth=6, seed=9)
+        accum = torch.zeros((W * H, 4), dtype=torch.int64, device="cuda")      # hpt_accum records
+        fixed = torch.zeros(W * H * 3, device="cuda")
+        st = sc.render_accum_device(accum.data_ptr(), 0, 0, W * H, want_stats=True, spp=n, first_sample=lo, max_depth=6, seed=9)
         rays = torch.tensor([float(st.rays_primary + st.rays_bounce)], dtype=torch.float64)
         dist.all_reduce(rays)
         reduce_sum(accum, dst=0)
+        sc.accum_resolve_device(accum.data_ptr(), fixed.data_ptr(), num_samples=11)
         # adaptive: rounds in lock step, min/max planes all-reduced, identical active sets
         eng = DeviceRounds(sc, max_depth=6, seed=9)
         rgb, spp = render_adaptive(eng, rank, world, initial_samples=8, max_samples=32)
         stream.synchronize()
         if rank == 0:
-            np.savez(out_path, fixed=(accum / 11.0).cpu().numpy(), rays=rays.numpy(), rgb=rgb.cpu().numpy(), spp=spp.cpu().numpy())
+            np.savez(out_path, fixed=fixed.cpu().numpy(), rays=rays.numpy(), rgb=rgb.cpu().numpy(), spp=spp.cpu().numpy())
     ctx.set_stream(0)
     sc.close()
     dist.barrier()
@@ -62,12 +64,12 @@ def test_two_processes_share_one_gpu(tmp_path, ctx, desc):
     two = np.load(out)
     sc = hpt.Scene(ctx, resized(desc, W, H), host_bvh=host_tree)
     one = sc.render(spp=11, max_depth=6, seed=9)
-    np.testing.assert_allclose(two["fixed"].reshape(H, W, 3), one["rgb"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_array_equal(two["fixed"].reshape(H, W, 3), one["rgb"])
     assert int(two["rays"][0]) == one["stats"].rays_primary + one["stats"].rays_bounce
     ad = sc.render(adaptive=True, initial=8, max_samples=32, max_depth=6, seed=9)
     np.testing.assert_array_equal(two["spp"].reshape(H, W), ad["samples"])
     assert len(np.unique(ad["samples"])) >= 2
-    np.testing.assert_allclose(two["rgb"].reshape(H, W, 3), ad["rgb"], rtol=3e-6, atol=1e-6)
+    np.testing.assert_array_equal(two["rgb"].reshape(H, W, 3), ad["rgb"])
     sc.close()
 
 
@@ -89,23 +91,30 @@ def test_group_render_behind_the_c_abi(ctx, desc, devices):
         assert r["stats"].n_devices == len(devices) and r["stats"].transport == (0 if len(devices) == 1 else 1)
         assert r["stats"].rays_primary + r["stats"].rays_bounce == one["stats"].rays_primary + one["stats"].rays_bounce
         assert (r["samples"] == 10).all()
-        if len(devices) == 1:
-            np.testing.assert_array_equal(r["rgb"], one["rgb"])
-        else:
-            np.testing.assert_allclose(r["rgb"], one["rgb"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_array_equal(r["rgb"], one["rgb"])      # any rank count: the one-context image, bit for bit
         # fewer samples than ranks: the surplus ranks contribute zeros
         few = g.render(sc, spp=2, max_depth=4, seed=5)
-        np.testing.assert_allclose(few["rgb"], hpt.Scene(ctx, d, host_bvh=host_tree).render(spp=2, max_depth=4, seed=5)["rgb"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_array_equal(few["rgb"], hpt.Scene(ctx, d, host_bvh=host_tree).render(spp=2, max_depth=4, seed=5)["rgb"])
         a = g.render(sc, adaptive=True, initial=8, max_samples=32, max_depth=6, seed=5)
         np.testing.assert_array_equal(a["samples"], ad["samples"])
-        np.testing.assert_allclose(a["rgb"], ad["rgb"], rtol=3e-6, atol=1e-6)
+        np.testing.assert_array_equal(a["rgb"], ad["rgb"])
         # the scene committed again (another camera): the replicas follow
         d2 = resized(desc, 40, 30)
         sc.set_camera(d2.camera); sc.commit()
         again = g.render(sc, spp=4, max_depth=4, seed=2)
         ref2 = hpt.Scene(ctx, d2, host_bvh=host_tree)
-        np.testing.assert_allclose(again["rgb"], ref2.render(spp=4, max_depth=4, seed=2)["rgb"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_array_equal(again["rgb"], ref2.render(spp=4, max_depth=4, seed=2)["rgb"])
         ref2.close()
+        # the scene destroyed and ANOTHER one built on the group's context (the allocator may well hand out the same address,
+        # and its first commit is "commit number one" again): the replicas must follow -- commit stamps are process-unique
+        sc.close()
+        d3 = resized(desc, W, H)
+        d3.nodes = [n for n in d3.nodes if n.geom != 1]      # no sphere
+        sc = hpt.Scene(g.context(0), d3, host_bvh=host_tree)
+        other = g.render(sc, spp=4, max_depth=4, seed=2)
+        ref3 = hpt.Scene(ctx, d3, host_bvh=host_tree)
+        np.testing.assert_array_equal(other["rgb"], ref3.render(spp=4, max_depth=4, seed=2)["rgb"])
+        ref3.close()
     finally:
         sc.close(); g.close()
 

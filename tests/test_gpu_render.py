@@ -159,7 +159,7 @@ def test_render_device_matches_host_entry(ctx, desc):
 
 
 def test_adaptive_rounds_api(ctx, olib, desc):
-    """hpt_render_round_device / hpt_adaptive_select_device (the per-rank pieces of a multi-GPU adaptive render):
+    """hpt_render_accum_device / hpt_adaptive_select_device (the per-rank pieces of a multi-GPU adaptive render):
     driven by hpt.dist.render_adaptive on one rank they reproduce hpt_render's adaptive mode exactly; a round split
     into two sample sub-ranges gives the same sums and min/max; scene info is reported."""
     import torch
@@ -203,23 +203,30 @@ def _adaptive_rounds_body(ctx, olib, d, sc, ref, stream):
         acc, mm, _ = eng.new_buffers(8)
         first = 0
         for cnt in split:
-            sc.render_round_device(acc.data_ptr(), mm.data_ptr(), plist.data_ptr(), len(plist), spp=cnt, first_sample=first, max_depth=4, seed=3)
+            sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), plist.data_ptr(), len(plist), spp=cnt, first_sample=first, max_depth=4, seed=3)
             first += cnt
         torch.cuda.synchronize()
         bufs.append((acc.cpu().numpy(), mm.cpu().numpy()))
     for acc, mm in bufs[1:]:
         np.testing.assert_array_equal(acc, bufs[0][0]); np.testing.assert_array_equal(mm, bufs[0][1])
     touched = np.zeros(npix, bool); touched[plist.cpu().numpy()] = True
-    assert (bufs[0][0].reshape(-1, 3)[~touched] == 0).all() and np.isinf(bufs[0][1][~touched, 0]).all()
-    # against the oracle's samples: per-pixel sums of samples 1..8
+    assert (bufs[0][0][~touched] == 0).all() and np.isinf(bufs[0][1][~touched, 0]).all()
+    # against the oracle's samples: per-pixel sums of samples 1..8 (fixed point, 2^-24 quantum; no NaN sample in this scene)
     per = ol.OracleScene(olib, d).render(spp=8, max_depth=4, seed=3, want_samples=True)["per_sample"]
     want = per[touched].astype(np.float64).sum(axis=1)
-    np.testing.assert_allclose(bufs[0][0].reshape(-1, 3)[touched], want, rtol=1e-5, atol=1e-6)
+    assert (bufs[0][0][:, 3] == 0).all()
+    np.testing.assert_allclose(bufs[0][0][touched, :3] / 2.0 ** 24, want, rtol=1e-5, atol=1e-6)
+    # ... and of the GPU's OWN samples bit for bit (tests/accum_ref.py restates the accumulator), resolved like the library does on the host
+    import accum_ref
+    own = sc.render_samples(spp=8, max_depth=4, seed=3)
+    mine = accum_ref.accumulate(np.zeros((npix, 4), dtype=np.int64), own[touched], rows=np.flatnonzero(touched))
+    np.testing.assert_array_equal(bufs[0][0], mine)
+    np.testing.assert_array_equal(hpt.accum_resolve(mine, num_samples=8), accum_ref.resolve(mine, num_samples=8))
     np.testing.assert_allclose(bufs[0][1][touched, :3], per[touched].min(axis=1), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(bufs[0][1][touched, 3:], per[touched].max(axis=1), rtol=1e-6, atol=1e-7)
     acc, mm, _ = eng.new_buffers(8)
     with pytest.raises(hpt.HptError):
-        sc.render_round_device(acc.data_ptr(), mm.data_ptr(), 0, 0, spp=4, adaptive=True)
+        sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), 0, 0, spp=4, adaptive=True)
 
 
 def test_progressive_checkpoint_resume(ctx, desc, tmp_path):
@@ -247,7 +254,8 @@ def test_progressive_checkpoint_resume(ctx, desc, tmp_path):
 
 def test_full_size_properties(ctx, desc):
     """BASELINE config-2 size (1920x1080, depth 8), where the oracle would take minutes: size-independent properties.
-    (1) linearity: doubling every emission doubles the image exactly (x2 is exact in f32, every path is unchanged);
+    (1) linearity: doubling every emission doubles every sample exactly (x2 is exact in f32, every path is unchanged), so the
+        fixed-point sums double up to the rounding of each sample to the 2^-24 quantum: |acc(2E) - 2 acc(E)| <= spp;
     (2) additivity over sample ranges: sums of samples [0,2) + [2,5) == sums of [0,5), bit for bit;
     (3) ray accounting: primary rays = W*H*spp, bounce rays <= primary * depth, and equal between the runs."""
     import copy
@@ -259,16 +267,21 @@ def test_full_size_properties(ctx, desc):
         m.emission = (m.emission * np.float32(2.0)).astype(np.float32)
     sc, sc2 = hpt.Scene(ctx, d, host_bvh=host_tree), hpt.Scene(ctx, d2, host_bvh=host_tree)
     npix = 1920 * 1080
-    a = torch.zeros(npix * 3, device="cuda"); b = torch.zeros(npix * 3, device="cuda"); c = torch.zeros(npix * 3, device="cuda")
+    a, b, c = (torch.zeros((npix, 4), dtype=torch.int64, device="cuda") for _ in range(3))      # hpt_accum records
+    img, img_c = torch.zeros(npix * 3, device="cuda"), torch.zeros(npix * 3, device="cuda")
     torch.cuda.synchronize()      # (torch's fills run on torch's stream, the library on the context's)
-    st_a = sc.render_device(a.data_ptr(), want_stats=True, spp=5, max_depth=8, seed=2)
-    st_b = sc2.render_device(b.data_ptr(), want_stats=True, spp=5, max_depth=8, seed=2)
+    st_a = sc.render_accum_device(a.data_ptr(), 0, 0, npix, want_stats=True, spp=5, max_depth=8, seed=2)
+    st_b = sc2.render_accum_device(b.data_ptr(), 0, 0, npix, want_stats=True, spp=5, max_depth=8, seed=2)
     assert st_a.rays_primary == npix * 5 and st_a.rays_bounce <= st_a.rays_primary * 8
     assert (st_a.rays_primary, st_a.rays_bounce) == (st_b.rays_primary, st_b.rays_bounce)
-    assert torch.equal(a * 2.0, b) and float(a.sum()) > 0
-    sc.render_round_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=2, first_sample=0, max_depth=8, seed=2)
-    sc.render_round_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=3, first_sample=2, max_depth=8, seed=2)
+    assert int((b[:, :3] - 2 * a[:, :3]).abs().max()) <= 5 and int(a[:, :3].sum()) > 0 and int(a[:, 3].sum()) == 0
+    sc.render_accum_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=2, first_sample=0, max_depth=8, seed=2)
+    sc.render_accum_device(c.data_ptr(), 0, 0, npix, want_stats=True, spp=3, first_sample=2, max_depth=8, seed=2)
     assert torch.equal(a, c)
+    # the float entry returns exactly these sums, rounded once
+    sc.render_device(img.data_ptr(), want_stats=True, spp=5, max_depth=8, seed=2)
+    sc.accum_resolve_device(c.data_ptr(), img_c.data_ptr()); ctx.synchronize()
+    assert torch.equal(img, img_c)
     sc.close(); sc2.close()
 
 

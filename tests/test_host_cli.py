@@ -166,6 +166,44 @@ def test_cli_renders_same_png(ctx, desc, tmp_path):
     sc.close()
 
 
+@pytest.mark.gpu
+def test_cli_checkpoint_resume(ctx, olib, desc, tmp_path):
+    """hpt_render --spp 5 --checkpoint f, then --resume f --spp 11 == --spp 16 in one go: PNG files byte-identical (the
+    accumulator is integer: splitting the samples over two runs changes no bit), the checkpoint files of both routes equal,
+    and the 16-spp image within 1e-3 rel-RMSE of the oracle's"""
+    import hpt
+    import oracle_lib as ol
+    from hpt import scene_io
+    from conftest import resized
+    scene_xml = os.path.join(GOLDEN, "scene.xml")
+    common = [scene_xml, None, "--size", "64x48", "--depth", "5", "--seed", "7"]
+
+    def run(out, *extra):
+        r = subprocess.run([CLI] + [out if a is None else a for a in common] + list(extra), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+    one, two, ck5, ck16a, ck16b = (str(tmp_path / n) for n in ("one.png", "two.png", "ck5.bin", "ck16a.bin", "ck16b.bin"))
+    run(one, "--spp", "16", "--checkpoint", ck16a)
+    run(str(tmp_path / "five.png"), "--spp", "5", "--checkpoint", ck5)
+    run(two, "--resume", ck5, "--spp", "11", "--checkpoint", ck16b)
+    assert open(one, "rb").read() == open(two, "rb").read()
+    assert open(ck16a, "rb").read() == open(ck16b, "rb").read() and os.path.getsize(ck16a) == 32 + 64 * 48 * 32
+    assert open(one, "rb").read() != open(str(tmp_path / "five.png"), "rb").read()
+    # the plain fixed-spp route (hpt_render) writes the same file
+    run(str(tmp_path / "plain.png"), "--spp", "16")
+    assert open(one, "rb").read() == open(str(tmp_path / "plain.png"), "rb").read()
+    # against the oracle: the accumulator file, resolved on the host
+    d = resized(desc, 64, 48)
+    ref = ol.OracleScene(olib, d).render(spp=16, max_depth=5, seed=7)["rgb"]
+    acc = np.fromfile(ck16a, dtype=np.int64, offset=32).reshape(-1, 4)
+    img = hpt.accum_resolve(acc, num_samples=16).reshape(48, 64, 3)
+    assert float(np.sqrt(((img - ref) ** 2).mean()) / ref.mean()) <= 1e-3
+    np.testing.assert_array_equal(scene_io.read_png_rgb8(one), hpt.tonemap_rgba8(img)[:, :, :3])
+    # a checkpoint of another seed is refused (exit 101 like every error of the reference's CLI)
+    r = subprocess.run([CLI, scene_xml, two, "--size", "64x48", "--depth", "5", "--seed", "8", "--resume", ck5, "--spp", "1"], capture_output=True, text=True)
+    assert r.returncode == 101 and "another frame size, seed or depth" in r.stderr
+
+
 def test_cli_rejects_bad_obj_indices(tmp_path):
     """out-of-range / zero / overflowing face indices: the reference panics when it indexes its Vecs; the C++ host must
     not read out of bounds (found by mutation fuzzing under ASan)"""
