@@ -540,6 +540,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     int tlas_min = 24;
     if (const char* e = getenv("HPT_TLAS_MIN")) tlas_min = atoi(e);
     int32_t use_tlas = 0, tlas_root = 0;
+    int32_t inst_base = 0x40000000, analytic_base = 0x60000000, restore_ref = (int32_t)~0x7ffffffe, stk16_ok = 0;
     s->tlas_nodes = 0;
     QuantFrame tlas_qf; std::memset(&tlas_qf, 0, sizeof tlas_qf);
     // padded world boxes of the instances: leaves of the TLAS
@@ -584,12 +585,23 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         if (!flatten_tree(tt, wb.data(), (int32_t)inst.size(), ft, err)) return fail(HPT_ERR_INVALID, "%s", err.c_str());
         const int64_t node_base = (int64_t)(nodes.size() / 16);
         if (node_base + ft.n_interior >= (1ll << 31)) return fail(HPT_ERR_LIMIT, "scene: more than 2^31 nodes");
-        // leaf refs: ~(0x40000000 + i) for a mesh instance, ~(0x60000000 + i) for a sphere / plane (the kernel defers those)
+        // leaf refs: ~(inst_base + i) for a mesh instance, ~(analytic_base + i) for a sphere / plane (the kernel may defer those);
+        // codes packed from 0 when they and the interior refs fit a signed 16-bit stack entry (hpt_device.h DScene.inst_base)
         if (inst.size() >= (1u << 26)) return fail(HPT_ERR_LIMIT, "scene: more than 2^26 instances");
+        const uint64_t n_tri_all = tris.size() / 12, n_codes = n_tri_all + 2 * (uint64_t)inst.size() + 1;
+        // ... for the scenes whose traversal tests everything in place (analytic instances below a quarter, triangle deferral off):
+        // that kernel variant then runs with a 16-bit stack at five waves per SIMD; the deferring variants are register-bound at four
+        size_t n_analytic = 0;
+        for (const DInstance& di : inst) n_analytic += di.geom != HPT_GEOM_MESH;
+        const char* e16 = getenv("HPT_TLAS_STK16"); const char* edef = getenv("HPT_TLAS_TRI_DEFER");
+        const bool want16 = !(e16 && atoi(e16) == 0) && !(edef && atoi(edef) != 0) && n_analytic * 4 < inst.size();
+        if (want16 && n_codes < 32767 && node_base + ft.n_interior < 32767) {
+            inst_base = (int32_t)n_tri_all; analytic_base = inst_base + (int32_t)inst.size(); restore_ref = ~(analytic_base + (int32_t)inst.size()); stk16_ok = 1;
+        }
         auto rebase = [&](int32_t ref) -> int32_t {
             if (ref >= 0) return (int32_t)(ref + node_base);
             const int32_t i = ~ref;
-            return ~(int32_t)((inst[(size_t)i].geom == HPT_GEOM_MESH ? 0x40000000 : 0x60000000) + i);
+            return ~(int32_t)((inst[(size_t)i].geom == HPT_GEOM_MESH ? inst_base : analytic_base) + i);
         };
         for (int32_t i = 0; i < ft.n_interior; ++i) {
             int32_t l, r;
@@ -659,7 +671,9 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     s->device_bytes = (node32 ? nodes32.size() : nodes.size()) * 4 + tris.size() * 4 + trishade.size() * 4 + inst.size() * sizeof(DInstance) + xinv.size() * sizeof(DXformInv) +
                       xfwd.size() * sizeof(DXformFwd) + mats.size() * sizeof(DMaterial) + pool.size();
     d.use_tlas = use_tlas; d.tlas_root = tlas_root;
-    d.node32 = node32 ? 1 : 0; d.pad0 = 0;
+    d.node32 = node32 ? 1 : 0; d.stk16_ok = stk16_ok;
+    d.inst_base = inst_base; d.analytic_base = analytic_base; d.restore_ref = restore_ref;
+    { const char* e = getenv("HPT_TLAS_TRI_DEFER"); d.tri_defer = (e && atoi(e) != 0) ? 1 : 0; }
     for (int k = 0; k < 3; ++k) { d.tlas_qbase[k] = tlas_qf.base[k]; d.tlas_qscale[k] = tlas_qf.scale[k]; }
     d.n_mesh_instances = (int32_t)meshinst.size(); d.n_nodes = (int32_t)(nodes.size() / 16);
     conv_texture(s->background, d.background); conv_texture(s->environment, d.environment);
@@ -857,9 +871,10 @@ static int extend_grid(const hpt_scene* s, int inflight) {
         per_cu = s->plan.extend_per_cu;
         if (per_cu <= 0)      // query failed: register budget of the kernels (hpt_kernels.hip) and LDS fit
             per_cu = std::min(4, (int)((160u * 1024u) / std::max<size_t>(s->plan.extend_lds, 1)));
-        // (instance-list kernel only; the two-level kernel: 10 k spheres +1 %, instanced teapots -2.5 %)
-        const int spare = ctx->extend_spare >= 0 ? ctx->extend_spare : std::max(per_cu - 4, 0);
-        if (inflight > 1 && !s->ds.use_tlas && per_cu > spare) per_cu -= spare;
+        // (two-level kernel: one slot -- r03c, HPT_EXTEND_BLOCKS_PER_CU sweep with two passes in flight: 3 375 instanced teapots
+        //  2 / 3 / 4 / 5 per CU of 5 resident = 2.86 / 3.17 / 3.21 / 3.11 Grays/s, 10 k spheres 2 / 3 / 4 of 4 = 4.19 / 4.27 / 4.15)
+        const int spare = ctx->extend_spare >= 0 ? ctx->extend_spare : (s->ds.use_tlas ? 1 : std::max(per_cu - 4, 0));
+        if (inflight > 1 && per_cu > spare) per_cu -= spare;
     }
     return ctx->num_cus * std::max(1, per_cu);
 }

@@ -135,7 +135,13 @@ struct DScene {
     const uint8_t* image_pool;
     int32_t n_instances, n_meshes, n_mesh_instances, n_nodes;
     int32_t use_tlas, tlas_root;     // two-level traversal (many instances): ref of the TLAS root in nodes[]
-    int32_t node32, pad0;            // 1: nodes[] holds Node32 records (2 quads per node), 0: Node64 (4 quads)
+    int32_t node32, stk16_ok;        // node32 = 1: nodes[] holds Node32 records (2 quads per node), 0: Node64 (4 quads); stk16_ok: see inst_base
+    // leaf codes of the two-level path: a leaf ref is ~code; code < inst_base = triangle (global index), < analytic_base = mesh instance
+    // (inst_base + i), else sphere / plane (analytic_base + i); restore_ref = the marker a ray pushes when it enters a mesh instance.
+    // 0x40000000 / 0x60000000 / ~0x7ffffffe -- or, when triangles + 2 x instances + the marker number below 32 767 and there are fewer
+    // than 32 767 interior nodes, packed from 0 (stk16_ok = 1: every stack entry fits a signed 16-bit word)
+    int32_t inst_base, analytic_base, restore_ref;
+    int32_t tri_defer;               // two-level path: deferred triangle tests (HPT_TLAS_TRI_DEFER=1 at commit; A/B variant, see hpt_kernels.hip tlas_meshes)
     float tlas_qbase[3], tlas_qscale[3];   // Node32 grid of the TLAS
     DTexture background, environment;
     DCamera cam;

@@ -49,6 +49,13 @@
 #ifndef HPT_PARK_INST
 #define HPT_PARK_INST 12
 #endif
+#ifndef HPT_TLAS_KEEP_WRB
+#define HPT_TLAS_KEEP_WRB 0      // two-level path: 1 = the world-space slab stays in registers while a mesh instance is walked instead of being rebuilt at
+                                 // the restore marker (measured +-0 on the 3 375 instanced teapots, 9 registers: profiles/r03c_tlas_tri_defer_ab.txt)
+#endif
+#ifndef HPT_TLAS16_WAVES
+#define HPT_TLAS16_WAVES 5       // two-level kernel with a 16-bit stack, triangles and analytic instances in place: register budget in waves per SIMD
+#endif
 
 // ------------------------------------------------------------------------------------------------ vector helpers
 struct f3 { float x, y, z; };
@@ -297,6 +304,7 @@ struct Lds {
     // deferred tests: per lane the best key of the ray it owns (t | triangle, or t | instance | side) + u, v, side of
     // that hit; per wave a pending list of (triangle or instance, owner lane) pairs waiting to be tested 64 at a time
     unsigned long long* best; float* du; float* dv; uint32_t* dsf; uint32_t* ltri; uint8_t* lown;
+    unsigned long long* abest; uint32_t* alist;      // two-level path: key and pending list of the deferred ANALYTIC instances
     float4* top;         // HPT_LDS_TOPCACHE variant: copy of the first HPT_LDS_TOPCACHE Node64 records
 };
 #define HPT_KEY_NONE 0x7f800000ffffffffull      // key of "no hit": t = +inf, no triangle / instance
@@ -315,13 +323,19 @@ __device__ __forceinline__ Lds lds_carve(int stack_entries, bool stk16 = false) 
     L.refill = 24; L.defer = false;
     return L;
 }
-// (`defer`: the host asks for key + list when a quarter of the scene's instances are analytic and the extra 5 KB do not
-//  cost a resident workgroup)
-__device__ __forceinline__ Lds lds_carve_tlas(int stack_entries, bool defer) {
+// (`defer`: the host asks for key + list of deferred analytic instances when a quarter of the scene's instances are analytic and
+//  the extra 4 KB do not cost a resident workgroup; `meshes`: scenes with mesh instances defer their triangle tests like the
+//  instance-list path -- key, u / v / side and the (triangle, owner) ring: 7.5 KB)
+__device__ __forceinline__ Lds lds_carve_tlas(int stack_entries, bool defer, bool meshes, bool stk16 = false) {
     Lds L = lds_carve(stack_entries);
     L.defer = defer;
-    L.best = (unsigned long long*)((unsigned char*)L.stack + (size_t)stack_entries * HPT_BLOCK * sizeof(int) + 16);
-    L.ltri = (uint32_t*)(L.best + HPT_BLOCK);
+    unsigned char* p = (unsigned char*)L.stack + (size_t)stack_entries * HPT_BLOCK * (stk16 ? sizeof(int16_t) : sizeof(int)) + 16;
+    L.abest = (unsigned long long*)p; L.alist = (uint32_t*)(L.abest + HPT_BLOCK);
+    if (defer) p = (unsigned char*)(L.alist + (HPT_BLOCK / 64) * HPT_LEAF_CAP);
+    L.best = (unsigned long long*)p;
+    L.du = (float*)(L.best + HPT_BLOCK); L.dv = L.du + HPT_BLOCK; L.dsf = (uint32_t*)(L.dv + HPT_BLOCK);
+    L.ltri = L.dsf + HPT_BLOCK; L.lown = (uint8_t*)(L.ltri + (HPT_BLOCK / 64) * HPT_LEAF_CAP);
+    (void)meshes;      // (the launch sizes the allocation: trav_lds_bytes)
     return L;
 }
 // Sharded wavefront queues.  A queue of capacity shards*cap slots is split into `shards` segments; segment s holds
@@ -799,18 +813,17 @@ __device__ __forceinline__ void block_closest_hit(const DScene& sc, Lds& L, cons
 // LDS stack; entering a mesh instance pushes HPT_REF_RESTORE, which brings the world-space ray back when popped.
 // Hits are order-independent: candidate (t, instance, triangle) replaces the best one iff it is lexicographically
 // smaller, which is the reference's rule "strictly nearer wins, earlier node wins ties" (scene.rs:196,251).
-#define HPT_INST_BASE 0x40000000
-#define HPT_REF_RESTORE ((int)~0x7ffffffe)
+// (the codes are per scene: DScene.inst_base / analytic_base / restore_ref -- 0x40000000 / 0x60000000 / ~0x7ffffffe, or small
+//  numbers when everything fits 15 bits, see TlasStack)
 // Deferred analytic instances of the two-level path: entries [first, first + n) of the wave's pending list (owner lane
 // << 26 | instance), one per lane.  The tester fetches the owner's WORLD ray through the LDS crossbar, walks the
 // instance's transform chain, runs the exact sphere / plane test and merges a hit into the owner's key with a 64-bit
 // LDS min: t bits << 32 | instance << 1 | side -- nearest hit, the earlier instance on equal t (scene.rs:196,251).
-#define HPT_ANALYTIC_BASE 0x60000000      // TLAS leaf refs: ~(HPT_INST_BASE + i) mesh instance, ~(HPT_ANALYTIC_BASE + i) sphere / plane
 template <bool COUNT>
 __device__ __forceinline__ void test_pending_analytic(const DScene& sc, const Lds& L, unsigned first, unsigned n, f3 o, f3 d, unsigned& n_inst) {
     const unsigned lane = threadIdx.x & 63u, wbase = threadIdx.x & ~63u, wave = threadIdx.x >> 6;
     const bool act = lane < n;
-    const uint32_t w = L.ltri[wave * HPT_LEAF_CAP + first + (act ? lane : 0u)];
+    const uint32_t w = L.alist[wave * HPT_LEAF_CAP + first + (act ? lane : 0u)];
     const int owner = (int)(w >> 26);
     const uint32_t i = w & 0x03ffffffu;
     f3 lo, ld;
@@ -827,38 +840,90 @@ __device__ __forceinline__ void test_pending_analytic(const DScene& sc, const Ld
         if (COUNT) n_inst++;
         float t; int s;
         const bool ok = in->geom == 1 ? intersect_sphere(lo, ld, t, s) : intersect_plane(lo, ld, t, s);
-        if (ok && t < HPT_INF) atomicMin(L.best + wbase + owner, ((unsigned long long)__float_as_uint(t) << 32) | (i << 1) | (uint32_t)s);
+        if (ok && t < HPT_INF) atomicMin(L.abest + wbase + owner, ((unsigned long long)__float_as_uint(t) << 32) | (i << 1) | (uint32_t)s);
     }
 }
 
 // Every wave is a persistent worker of its own (no workgroup barrier): it walks the 64-slot pieces x = global wave,
 // + number of waves, ... of the input (piece x = quarter x % 4 of chunk x / 4) and hands their rays to lanes as they
 // fall idle, so under-filled steps only occur at the very end of the launch.
-template <bool COUNT, bool NODE32, bool DEFER, bool DYNAMIC = false>
+// MESHES (scenes with mesh instances; round 3): TRIANGLE TESTS ARE DEFERRED like on the instance-list path.  A leaf child whose box
+// the ray enters is not walked into: (triangle, owner lane) goes to the wave's ring and 64 of them are tested at a time with the
+// owner's mesh-local ray (test_pending); the nearest triangle of the instance being visited collects in the owner's LDS key.
+// The owner does not wait for its tests: it goes on with box steps, leaves the instance (the world-space slab is KEPT in
+// registers: no make_raybox / quant_slab at the restore marker) and walks on through the TLAS while its mesh-local ray stays
+// in (co, cd) for the testers.  Only when it is about to enter its NEXT mesh instance -- or is finished -- must its entries
+// have been tested; the key is then merged into the ray's hit by the lexicographic rule.  r02g tested triangles in place once
+// 12 lanes of the wave had parked at one (19 % of the lanes in the 90-instruction block, and parked lanes sat out box steps):
+// VALU 0.87 busy at 0.41 lane utilisation on the 3 375 instanced teapots (profiles/r03b_instanced_pmc_valu.json).
+// Mesh-instance entries (chain, root box, slab: ~90 instructions) are still run in place by parked lanes: the owner needs
+// the result before it can take another step.
+// The one stack of the two-level path.  STK16: entries are 16 bits wide and signed -- possible when hpt_scene_commit could number the
+// scene's leaf codes (triangles, mesh instances, analytic instances, the restore marker) below 32 767 and there are fewer than
+// 32 767 interior nodes (3 375 instanced teapots: 34 entries = 17 instead of 34 KB per workgroup; LDS no longer caps the
+// resident workgroups at four).  The sentinel is entry 0 and never stored.
+template <bool STK16> struct TlasStack;
+template <> struct TlasStack<false> {
+    int* p;
+    __device__ __forceinline__ TlasStack(const Lds& L) : p(L.stack + threadIdx.x) {}
+    __device__ __forceinline__ void put(int sp, int ref) { p[sp * HPT_BLOCK] = ref; }
+    __device__ __forceinline__ int get(int sp) const { return p[sp * HPT_BLOCK]; }
+};
+template <> struct TlasStack<true> {
+    int16_t* p;
+    __device__ __forceinline__ TlasStack(const Lds& L) : p((int16_t*)L.stack + threadIdx.x) {}
+    __device__ __forceinline__ void put(int sp, int ref) { p[sp * HPT_BLOCK] = (int16_t)ref; }
+    __device__ __forceinline__ int get(int sp) const { const int v = (int)p[sp * HPT_BLOCK]; return sp == 0 ? (int)0x80000000 : v; }
+};
+template <bool COUNT, bool NODE32, bool DEFER, bool DYNAMIC = false, bool MESHES = true, bool STK16 = false, bool RTCODES = STK16>
 __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L, const WorkView& wv, const float4* __restrict__ ray_o,
                                                        const float4* __restrict__ ray_d, float4* __restrict__ hit, uint32_t* __restrict__ hit_inst,
                                                        unsigned& n_int, unsigned& n_tri, unsigned& n_inst) {
     constexpr unsigned WAVES = HPT_BLOCK / 64;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    int* stk = L.stack + threadIdx.x;
+    TlasStack<STK16> stk(L);
     const int SENTINEL = (int)0x80000000;
+    // leaf codes of this scene (hpt_scene_commit): ~ref < inst_base a triangle, < analytic_base a mesh instance, else a sphere / plane
+    // (packed from 0 only for the scenes that run the STK16 variant; compile-time constants otherwise)
+    // (RTCODES: the test entry serves every scene with one set of variants and reads them from the scene)
+    const uint32_t inst_base = RTCODES ? (uint32_t)sc.inst_base : 0x40000000u, analytic_base = RTCODES ? (uint32_t)sc.analytic_base : 0x60000000u;
+    const int restore_ref = RTCODES ? sc.restore_ref : (int)~0x7ffffffe;
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
     PieceFeed<DYNAMIC> feed(wv);
     uint32_t piece_slot = 0, piece_n = 0, piece_pos = 0;      // wave-uniform: the piece rays are being handed out from
-    const bool park = sc.n_mesh_instances > 0;
-    unsigned long long* mybest = L.best + threadIdx.x;        // best analytic hit of the lane's ray: t bits << 32 | instance << 1 | side
+    const bool park = sc.n_mesh_instances > 0;               // (in-place triangle tests; scenes without mesh instances have nothing worth waiting for)
+    unsigned long long* mybest = L.abest + threadIdx.x;       // best analytic hit of the lane's ray: t bits << 32 | instance << 1 | side
+    unsigned long long* mytri = L.best + threadIdx.x;         // MESHES: nearest triangle of the mesh instance being visited: t bits << 32 | triangle
     const unsigned lbase = wave * HPT_LEAF_CAP;
     unsigned pend = 0;                                        // wave-uniform: analytic instances waiting to be tested
+    uint32_t qhead = 0, qtail = 0;                            // wave-uniform: triangle ring, entries [qhead, qtail) pending (entry e at e % HPT_LEAF_CAP)
+    uint32_t my_last = 0;                                     // sequence number + 1 of the lane's last entry: all tested once my_last <= qhead
     bool have = false, input_done = false;
+    bool open = false;                                        // a mesh instance was entered and its key is not merged into h yet
     uint32_t slot = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), co = o, cd = d;
     Hit h; h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
-    RayBox rb = make_raybox(co, cd);
-    float ta = HPT_INF;                                       // t of *mybest as of the last batch (culling bound)
+    RayBox rb = make_raybox(co, cd), wrb = rb;                // slab of the space being walked / of the world-space ray on the TLAS grid
+    float ta = HPT_INF, tb = HPT_INF;                         // t of *mybest / *mytri as of the last batch (culling bounds; t is the same parameter in every space)
     int ref = SENTINEL, sp = 1; uint32_t cur_inst = 0;
+    // nearest triangle of the instance visit `cur_inst` -> the ray's hit: lexicographic (t, instance, triangle)
+    auto merge_open = [&]() {
+        const unsigned long long key = *mytri;
+        if ((uint32_t)key != 0xffffffffu) {
+            const uint32_t sf = L.dsf[threadIdx.x];
+            const float t = (sf & 2u) ? -0.0f : __uint_as_float((uint32_t)(key >> 32));
+            const uint32_t x = (uint32_t)key, bi = h.inst_side & 0x7fffffffu;
+            if (t < h.t || (t == h.t && (cur_inst < bi || (cur_inst == bi && (int)x < h.prim)))) {
+                h.t = t; h.u = L.du[threadIdx.x]; h.v = L.dv[threadIdx.x]; h.prim = (int)x; h.inst_side = cur_inst | ((sf & 1u) << 31);
+            }
+            *mytri = HPT_KEY_NONE;
+        }
+        open = false; tb = HPT_INF;
+    };
     for (;;) {
-        if (have && ref == SENTINEL) {   // ray finished (nothing of it is pending: the list was emptied below)
+        if (have && ref == SENTINEL) {   // ray finished (nothing of it is pending: the lists were emptied below)
+            if (MESHES && open) merge_open();
             const unsigned long long key = DEFER ? *mybest : HPT_KEY_NONE;
             if ((uint32_t)key != 0xffffffffu) {
                 const float t = __uint_as_float((uint32_t)(key >> 32));
@@ -892,9 +957,11 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
                 o = xyz(ray_o[slot]); d = xyz(ray_d[slot]); co = o; cd = d;
                 rb = make_raybox(o, d);
                 if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
+                if (MESHES || HPT_TLAS_KEEP_WRB) wrb = rb;
+                if (MESHES) { *mytri = HPT_KEY_NONE; open = false; tb = HPT_INF; }
                 h.t = HPT_INF; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = HPT_MISS_INST;
                 ta = HPT_INF; if (DEFER) *mybest = HPT_KEY_NONE;
-                stk[0] = SENTINEL; sp = 1; ref = sc.tlas_root;
+                stk.put(0, SENTINEL); sp = 1; ref = sc.tlas_root;
                 have = true;
             }
             piece_pos += take;
@@ -903,54 +970,77 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
         const int keep_going_above = input_done ? 0 : 64 - L.refill;
         while (__popcll(__ballot(have && ref != SENTINEL)) > keep_going_above) {
             bool anaL = false, anaR = false; int l = 0, r = 0;
-            // Parking: a lane that holds a triangle or an instance leaf waits until HPT_PARK_TRI / HPT_PARK_INST lanes of the wave hold the same
-            // kind (or no lane has a box step left), so the long, rarely needed blocks run in few steps with many lanes
-            // instead of in every step with three or four.
+            int cl = 0, cr = 0;      // MESHES: triangle refs (negative) for the ring, else 0
             const bool at_leaf = have && ref < 0 && ref != SENTINEL;
-            const bool at_tri = at_leaf && (uint32_t)~ref < (uint32_t)HPT_INST_BASE;
-            const bool at_inst = at_leaf && !at_tri && ref != HPT_REF_RESTORE;
-            bool go_tri = true, go_inst = true;
-            if (park) {      // (scenes without mesh instances have nothing worth waiting for)
+            const bool at_inst = at_leaf && ref != restore_ref && (uint32_t)~ref >= inst_base;
+            const bool at_tri = at_leaf && (uint32_t)~ref < inst_base;
+            bool go_tri = true;
+            // Parking: a lane that holds an instance leaf waits until HPT_PARK_INST lanes of the wave do (or no lane has a box step
+            // left), so the long block runs in few steps with many lanes instead of in every step with three or four.  A lane whose
+            // previous instance still has triangle tests pending is not ready: entering would overwrite the ray those tests read.
+            bool go_inst = true;
+            if (MESHES) {
+                const bool no_box_step = __ballot(have && ref >= 0) == 0ull;
+                const bool ready = at_inst && (!open || my_last <= qhead);
+                const int n_ready = __popcll(__ballot(ready));
+                // no lane can take a step (every walking lane waits at an instance for its pending tests): leave the loop, the
+                // lists are emptied behind it
+                if (no_box_step && n_ready == 0 && __ballot(at_leaf && !at_inst) == 0ull) break;
+                go_inst = ready && (no_box_step || n_ready >= HPT_PARK_INST);
+                if (open && go_inst) merge_open();      // (ready: every test of the previous instance has run)
+            } else if (park) {      // triangles tested in place: lanes at a triangle / an instance leaf wait for HPT_PARK_TRI / HPT_PARK_INST of their kind
                 const bool no_box_step = __ballot(have && ref >= 0) == 0ull;
                 go_tri = no_box_step || __popcll(__ballot(at_tri)) >= HPT_PARK_TRI;
                 go_inst = no_box_step || __popcll(__ballot(at_inst)) >= HPT_PARK_INST;
             }
+            const float bound_s = fminf(fminf(h.t, ta), tb) * HPT_SLACK;
             if (have && ref >= 0) {
                 if (COUNT) n_int++;
                 bool hitL, hitR; float tinL, tinR;
-                test_children<NODE32>(nodes, ref, rb, fminf(h.t, ta) * HPT_SLACK, hitL, hitR, tinL, tinR, l, r);
-                // a child that is an analytic instance (sphere / plane) is not walked into: it goes to the pending list
-                anaL = DEFER && hitL && l < 0 && (uint32_t)~l >= (uint32_t)HPT_ANALYTIC_BASE;
-                anaR = DEFER && hitR && r < 0 && (uint32_t)~r >= (uint32_t)HPT_ANALYTIC_BASE;
-                hitL = hitL && !anaL; hitR = hitR && !anaR;
+                test_children<NODE32>(nodes, ref, rb, bound_s, hitL, hitR, tinL, tinR, l, r);
+                // a child that is an analytic instance (sphere / plane) or a triangle is not walked into: it goes to its pending list
+                anaL = DEFER && hitL && l < 0 && (uint32_t)~l >= analytic_base;
+                anaR = DEFER && hitR && r < 0 && (uint32_t)~r >= analytic_base;
+                const bool triL = MESHES && hitL && l < 0 && (uint32_t)~l < inst_base;
+                const bool triR = MESHES && hitR && r < 0 && (uint32_t)~r < inst_base;
+                if (triL) cl = l;
+                if (triR) cr = r;
+                hitL = hitL && !anaL && !triL; hitR = hitR && !anaR && !triR;
                 if (hitL && hitR) {
                     const bool lfirst = tinL < tinR;
-                    stk[sp * HPT_BLOCK] = lfirst ? r : l;
+                    stk.put(sp, lfirst ? r : l);
                     sp++;
                     ref = lfirst ? l : r;
                 } else if (hitL) ref = l;
                 else if (hitR) ref = r;
-                else { --sp; ref = stk[sp * HPT_BLOCK]; }
-            } else if (at_leaf && (at_tri ? go_tri : (at_inst ? go_inst : true))) {
+                else { --sp; ref = stk.get(sp); }
+            } else if (at_leaf && (at_inst ? go_inst : (at_tri ? go_tri : true))) {
                 const uint32_t x = (uint32_t)~ref;
                 bool pop = true;
-                if (x < (uint32_t)HPT_INST_BASE) {            // triangle of the mesh instance being walked
-                    const float4* tq = tris + x * (uint32_t)HPT_TRI_QUADS;
-                    const float4 a = tq[0], ab = tq[1], ac = tq[2];
-                    if (COUNT) n_tri++;
-                    float t, u, v; int s;
-                    if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), co, cd, t, u, v, s)) {
-                        const uint32_t bi = h.inst_side & 0x7fffffffu;
-                        if (t < h.t || (t == h.t && (cur_inst < bi || (cur_inst == bi && (int)x < h.prim)))) {
-                            h.t = t; h.u = u; h.v = v; h.prim = (int)x; h.inst_side = cur_inst | ((uint32_t)s << 31);
+                if (x < inst_base) {            // a triangle as `ref`: a mesh whose root is a leaf
+                    if constexpr (MESHES) cl = ref;
+                    else {
+                        const float4* tq = tris + x * (uint32_t)HPT_TRI_QUADS;
+                        const float4 a = tq[0], ab = tq[1], ac = tq[2];
+                        if (COUNT) n_tri++;
+                        float t, u, v; int s;
+                        if (intersect_triangle(xyz(a), xyz(ab), xyz(ac), co, cd, t, u, v, s)) {
+                            const uint32_t bi = h.inst_side & 0x7fffffffu;
+                            if (t < h.t || (t == h.t && (cur_inst < bi || (cur_inst == bi && (int)x < h.prim)))) {
+                                h.t = t; h.u = u; h.v = v; h.prim = (int)x; h.inst_side = cur_inst | ((uint32_t)s << 31);
+                            }
                         }
                     }
-                } else if (ref == HPT_REF_RESTORE) {          // back from a mesh instance to the world-space ray
-                    co = o; cd = d; rb = make_raybox(o, d);
-                    if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
+                } else if (ref == restore_ref) {          // back from a mesh instance to the world-space ray
+                    if constexpr (MESHES) rb = wrb;           // (co, cd keep the mesh-local ray: tests of this instance may still be pending)
+                    else if constexpr (HPT_TLAS_KEEP_WRB) { co = o; cd = d; rb = wrb; }
+                    else {
+                        co = o; cd = d; rb = make_raybox(o, d);
+                        if (NODE32) rb = quant_slab(rb, sc.tlas_qbase, sc.tlas_qscale);
+                    }
                 } else {                                      // TLAS leaf: an instance (DEFER: a mesh instance -- analytic ones
                                                               // never reach the stack, the TLAS root is an interior node)
-                    const uint32_t i = (!DEFER && x >= (uint32_t)HPT_ANALYTIC_BASE) ? x - (uint32_t)HPT_ANALYTIC_BASE : x - (uint32_t)HPT_INST_BASE;
+                    const uint32_t i = (!DEFER && x >= analytic_base) ? x - analytic_base : x - inst_base;
                     const DInstance* in = sc.instances + i;
                     f3 lo = o, ld = d;
                     ray_level(in->lv[0], lo, ld);
@@ -968,10 +1058,11 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
                         if (box_hit(lrb, make_float3(mesh->bmin[0], mesh->bmin[1], mesh->bmin[2]), make_float3(mesh->bmax[0], mesh->bmax[1], mesh->bmax[2]), fminf(h.t, ta) * HPT_SLACK, tin)) {
                             co = lo; cd = ld; cur_inst = i;
                             rb = NODE32 ? quant_slab(lrb, mesh->qbase, mesh->qscale) : lrb;
-                            stk[sp * HPT_BLOCK] = HPT_REF_RESTORE;
+                            stk.put(sp, restore_ref);
                             sp++;
                             ref = mesh->root_ref;
                             pop = false;
+                            if (MESHES) open = true;
                         }
                     } else {
                         float t; int s;
@@ -979,19 +1070,33 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
                         if (ok && (t < h.t || (t == h.t && i < (h.inst_side & 0x7fffffffu)))) { h.t = t; h.u = 0.0f; h.v = 0.0f; h.prim = -1; h.inst_side = i | ((uint32_t)s << 31); }
                     }
                 }
-                if (pop) { --sp; ref = stk[sp * HPT_BLOCK]; }
+                if (pop) { --sp; ref = stk.get(sp); }
             }
-            if constexpr (!DEFER) continue;
-            const unsigned long long mL = __ballot(anaL), mR = __ballot(anaR);
-            if (mL | mR) {      // (a batch is tested between the two sides: at most 63 + 64 entries, HPT_LEAF_CAP 128)
-                bool tested = false;
-                if (anaL) L.ltri[lbase + pend + lane_prefix(mL)] = (lane << 26) | ((uint32_t)~l - (uint32_t)HPT_ANALYTIC_BASE);
-                pend += (unsigned)__popcll(mL);
-                if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); tested = true; }
-                if (anaR) L.ltri[lbase + pend + lane_prefix(mR)] = (lane << 26) | ((uint32_t)~r - (uint32_t)HPT_ANALYTIC_BASE);
-                pend += (unsigned)__popcll(mR);
-                if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); tested = true; }
-                if (tested) ta = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
+            if constexpr (DEFER) {
+                const unsigned long long mL = __ballot(anaL), mR = __ballot(anaR);
+                if (mL | mR) {      // (a batch is tested between the two sides: at most 63 + 64 entries, HPT_LEAF_CAP 128)
+                    bool tested = false;
+                    if (anaL) L.alist[lbase + pend + lane_prefix(mL)] = (lane << 26) | ((uint32_t)~l - analytic_base);
+                    pend += (unsigned)__popcll(mL);
+                    if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); tested = true; }
+                    if (anaR) L.alist[lbase + pend + lane_prefix(mR)] = (lane << 26) | ((uint32_t)~r - analytic_base);
+                    pend += (unsigned)__popcll(mR);
+                    if (pend >= 64u) { pend -= 64u; test_pending_analytic<COUNT>(sc, L, pend, 64u, o, d, n_inst); tested = true; }
+                    if (tested) ta = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
+                }
+            }
+            if constexpr (MESHES) {
+                const unsigned long long mL = __ballot(cl < 0), mR = __ballot(cr < 0);
+                if (mL | mR) {      // (ring: at most 63 + 64 entries at any time)
+                    bool tested = false;
+                    if (cl < 0) { const uint32_t q = qtail + lane_prefix(mL); const unsigned e = lbase + (q & (uint32_t)(HPT_LEAF_CAP - 1)); L.ltri[e] = (uint32_t)~cl; L.lown[e] = (uint8_t)lane; my_last = q + 1u; }
+                    qtail += (uint32_t)__popcll(mL);
+                    if (qtail - qhead >= 64u) { test_pending<COUNT, true>(L, tris, qhead, 64u, co, cd, n_tri); qhead += 64u; tested = true; }
+                    if (cr < 0) { const uint32_t q = qtail + lane_prefix(mR); const unsigned e = lbase + (q & (uint32_t)(HPT_LEAF_CAP - 1)); L.ltri[e] = (uint32_t)~cr; L.lown[e] = (uint8_t)lane; my_last = q + 1u; }
+                    qtail += (uint32_t)__popcll(mR);
+                    if (qtail - qhead >= 64u) { test_pending<COUNT, true>(L, tris, qhead, 64u, co, cd, n_tri); qhead += 64u; tested = true; }
+                    if (tested) tb = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mytri >> 32));
+                }
             }
         }
         // ---- what is still pending is tested before any lane retires its ray
@@ -1001,6 +1106,14 @@ __device__ __forceinline__ void block_closest_hit_tlas(const DScene& sc, Lds& L,
             test_pending_analytic<COUNT>(sc, L, pend, n, o, d, n_inst);
         }
         if (DEFER) ta = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mybest >> 32));
+        if constexpr (MESHES) {
+            while (qhead != qtail) {
+                const unsigned n = qtail - qhead < 64u ? qtail - qhead : 64u;
+                test_pending<COUNT, true>(L, tris, qhead, n, co, cd, n_tri);
+                qhead += n;
+            }
+            tb = __uint_as_float((uint32_t)(*(volatile unsigned long long*)mytri >> 32));
+        }
     }
 }
 
@@ -1110,11 +1223,13 @@ k_halton(float2* __restrict__ out, uint32_t first_sample, uint32_t n) {
 // DEFER (two-level only): analytic instances go through the pending list (the launch then carves key + list in LDS)
 // DYN: input pieces come through the work counter of this depth (always for the two-level path; for the instance-list
 // path when the rays are expensive -- big trees -- see extend_kernel)
-template <bool COUNT, bool TLAS, bool NODE32, bool DEFER, bool DYN, bool STK16 = false>
-__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(TLAS ? 4 : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES), TLAS ? 4 : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES))))
+// MESHES (two-level only): the scene has mesh instances -> deferred triangle tests (block_closest_hit_tlas)
+template <bool COUNT, bool TLAS, bool NODE32, bool DEFER, bool DYN, bool STK16 = false, bool MESHES = false>
+#define HPT_EXTEND_WAVES_OF(TLAS, STK16, DEFER, MESHES) (TLAS ? ((STK16 && !DEFER && !MESHES) ? HPT_TLAS16_WAVES : 4) : (STK16 ? HPT_EXTEND16_WAVES : HPT_EXTEND_WAVES))
+__global__ void __launch_bounds__(HPT_BLOCK) __attribute__((amdgpu_waves_per_eu(HPT_EXTEND_WAVES_OF(TLAS, STK16, DEFER, MESHES), HPT_EXTEND_WAVES_OF(TLAS, STK16, DEFER, MESHES))))
 k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
-    // STK16 (instance-list path, scenes of fewer than 65 535 nodes): 16-bit stack entries
-    Lds L = TLAS ? lds_carve_tlas(stack_entries, DEFER) : lds_carve(stack_entries, STK16);
+    // STK16: 16-bit stack entries (instance-list path: scenes of fewer than 65 535 nodes; two-level path: DScene.stk16_ok)
+    Lds L = TLAS ? lds_carve_tlas(stack_entries, DEFER, MESHES, STK16) : lds_carve(stack_entries, STK16);
     L.refill = refill;
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0;
@@ -1127,7 +1242,7 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
         __syncthreads();
     }
 #endif
-    if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true, MESHES, STK16>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
     else {
         wv.counts = ps.counts + HPT_MQ_COUNTS(depth);      // instance-list path: the input is the mesh queue k_extend_a filled
         block_closest_hit<COUNT, NODE32, false, DYN, STK16, true>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
@@ -1306,14 +1421,23 @@ __global__ void __launch_bounds__(HPT_BLOCK)
 k_scene_closest(DScene sc, long long n, const float4* __restrict__ org, const float4* __restrict__ dir,
                 float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, int stack_entries, int defer,
                 const uint2* __restrict__ mq, const uint32_t* __restrict__ mq_count, uint32_t mq_cap) {
-    Lds L = sc.use_tlas ? lds_carve_tlas(stack_entries, defer != 0) : lds_carve(stack_entries);
+    const bool meshes = (defer & 2) != 0;      // deferred triangle tests (tlas_meshes on the host)
+    defer &= 1;
+    Lds L = sc.use_tlas ? lds_carve_tlas(stack_entries, defer != 0, meshes) : lds_carve(stack_entries);
     unsigned c0 = 0, c1 = 0, c2 = 0;
     WorkView wv; wv.counts = nullptr; wv.shards = 1; wv.n_linear = (uint32_t)n; wv.work = nullptr;
     wv.cap = (uint32_t)((n + HPT_BLOCK - 1) / HPT_BLOCK) * HPT_BLOCK;
     if (!sc.use_tlas) { wv.counts = mq_count; wv.shards = HPT_SHARDS; wv.cap = mq_cap; }
     if (sc.use_tlas) {
-        if (defer) { if (sc.node32) block_closest_hit_tlas<false, true, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit_tlas<false, false, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
-        else { if (sc.node32) block_closest_hit_tlas<false, true, false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit_tlas<false, false, false>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2); }
+#define HPT_TLAS_CASE(N32, DEF, MSH) block_closest_hit_tlas<false, N32, DEF, false, MSH, false, true>(sc, L, wv, org, dir, hit, hit_inst, c0, c1, c2)
+        if (meshes) {
+            if (defer) { if (sc.node32) HPT_TLAS_CASE(true, true, true); else HPT_TLAS_CASE(false, true, true); }
+            else { if (sc.node32) HPT_TLAS_CASE(true, false, true); else HPT_TLAS_CASE(false, false, true); }
+        } else {
+            if (defer) { if (sc.node32) HPT_TLAS_CASE(true, true, false); else HPT_TLAS_CASE(false, true, false); }
+            else { if (sc.node32) HPT_TLAS_CASE(true, false, false); else HPT_TLAS_CASE(false, false, false); }
+        }
+#undef HPT_TLAS_CASE
     }
     else { if (sc.node32) block_closest_hit<false, true>(sc, L, wv, mq, org, dir, hit, hit_inst, c0, c1, c2); else block_closest_hit<false, false>(sc, L, wv, mq, org, dir, hit, hit_inst, c0, c1, c2); }
 }
@@ -1617,13 +1741,20 @@ static inline int grid_for(uint64_t n, int max_blocks) {
 static inline int carve_entries(int stack_entries, bool tlas) { return tlas ? stack_entries : (stack_entries > 2 ? stack_entries - 1 : stack_entries); }
 // dynamic LDS of the traversal kernels (see lds_carve / lds_carve_tlas): the stack alone, + the
 // deferred-triangle areas (instance-list path), or + key and pending list of deferred analytic instances (two-level path)
+// (two-level path: LDS_STACK / LDS_TLAS = without / with the key and list of deferred analytic instances; `meshes` adds the
+//  deferred-triangle areas of a scene with mesh instances)
 enum { LDS_STACK = 0, LDS_LIST = 1, LDS_TLAS = 2 };
-static inline size_t trav_lds_bytes(int stack_entries, int mode, bool stk16 = false) {
+static inline size_t trav_lds_bytes(int stack_entries, int mode, bool stk16 = false, bool meshes = false) {
     size_t n = (size_t)stack_entries * HPT_BLOCK * (stk16 ? sizeof(uint16_t) : sizeof(int)) + 16;
-    if (mode == LDS_LIST) n += (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 + (HPT_LDS_TOPCACHE ? 16 + (size_t)HPT_LDS_TOPCACHE * 32 : 0);
+    if (mode == LDS_LIST || meshes) n += (size_t)HPT_BLOCK * 20 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 5 + ((HPT_LDS_TOPCACHE && mode == LDS_LIST) ? 16 + (size_t)HPT_LDS_TOPCACHE * 32 : 0);
     if (mode == LDS_TLAS) n += (size_t)HPT_BLOCK * 8 + (size_t)(HPT_BLOCK / 64) * HPT_LEAF_CAP * 4;
     return n;
 }
+// Deferred triangle tests on the two-level path (block_closest_hit_tlas MESHES): built and measured in round 3 on the 3 375 instanced
+// teapots -- at equal occupancy it equals the in-place form (6.42 vs 6.44 ms per launch: fewer instructions, 7 % more box steps
+// and 17 % more triangle tests from the later bounds) and its 7.7 KB of LDS cost the fourth workgroup per CU (5.45 ms):
+// profiles/r03c_tlas_tri_defer_ab.txt.  HPT_TLAS_TRI_DEFER=1 selects it.
+static inline bool tlas_meshes(const DScene& sc) { return sc.use_tlas && sc.tri_defer && sc.n_mesh_instances > 0; }      // (read at hpt_scene_commit)
 
 template <typename K>
 static int resident_blocks(K k, size_t lds) {
@@ -1641,6 +1772,7 @@ static inline bool extend_dynamic(const DScene& sc) {
     return forced >= 0 ? forced != 0 : sc.n_nodes >= 65536;
 }
 static inline bool extend_stk16(const DScene& sc) { return !sc.use_tlas && sc.n_nodes < 65535; }      // every interior ref fits 16 bits beside the 0xffff that is never one
+static inline bool tlas_stk16(const DScene& sc) { return sc.use_tlas && sc.stk16_ok; }      // hpt_scene_commit numbered the leaf codes for it
 template <bool COUNT>
 static auto extend_kernel(const DScene& sc, bool defer) -> void (*)(DScene, DPass, int, int, int) {
     if (!sc.use_tlas) {
@@ -1651,6 +1783,11 @@ static auto extend_kernel(const DScene& sc, bool defer) -> void (*)(DScene, DPas
         if (extend_dynamic(sc)) return sc.node32 ? k_extend<COUNT, false, true, false, true> : k_extend<COUNT, false, false, false, true>;
         return sc.node32 ? k_extend<COUNT, false, true, false, false> : k_extend<COUNT, false, false, false, false>;
     }
+    if (tlas_meshes(sc)) {
+        if (defer) return sc.node32 ? k_extend<COUNT, true, true, true, true, false, true> : k_extend<COUNT, true, false, true, true, false, true>;
+        return sc.node32 ? k_extend<COUNT, true, true, false, true, false, true> : k_extend<COUNT, true, false, false, true, false, true>;
+    }
+    if (tlas_stk16(sc) && !defer) return sc.node32 ? k_extend<COUNT, true, true, false, true, true> : k_extend<COUNT, true, false, false, true, true>;
     if (defer) return sc.node32 ? k_extend<COUNT, true, true, true, true> : k_extend<COUNT, true, false, true, true>;
     return sc.node32 ? k_extend<COUNT, true, true, false, true> : k_extend<COUNT, true, false, false, true>;
 }
@@ -1660,9 +1797,11 @@ static int extend_resident(const DScene& sc, bool defer, size_t lds) { return re
 // resident workgroup; else they test them in place (3 375 teapots over one floor plane: deferral measured +26 %).
 static int scene_lds_mode(int stack_entries, const DScene& sc) {
     if (!sc.use_tlas) return LDS_LIST;
-    if ((sc.n_instances - sc.n_mesh_instances) * 4 < sc.n_instances) return LDS_STACK;
-    const int with = extend_resident(sc, true, trav_lds_bytes(stack_entries, LDS_TLAS)), without = extend_resident(sc, false, trav_lds_bytes(stack_entries, LDS_STACK));
-    return (with > 0 && with >= without) ? LDS_TLAS : LDS_STACK;
+    if ((sc.n_instances - sc.n_mesh_instances) * 4 < sc.n_instances || sc.stk16_ok) return LDS_STACK;      // (stk16_ok: committed for the in-place variant)
+    const bool m = tlas_meshes(sc);
+    const int with = extend_resident(sc, true, trav_lds_bytes(stack_entries, LDS_TLAS, false, m)), without = extend_resident(sc, false, trav_lds_bytes(stack_entries, LDS_STACK, false, m));
+    // (four resident workgroups are enough for it: the in-place variant with a 16-bit stack reaches five, and on 10 k spheres it is still 17 % slower)
+    return (with > 0 && (with >= without || with >= 4)) ? LDS_TLAS : LDS_STACK;
 }
 // slots of a mesh queue sharded HPT_SHARDS ways for n rays in 256-ray chunks (chunk c appends to segment c % HPT_SHARDS)
 size_t hptk_mq_slots(uint64_t n) {
@@ -1700,7 +1839,7 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
         hipLaunchKernelGGL(k_scene_analytic, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, mq, mq_count, (uint32_t)(hptk_mq_slots((uint64_t)n) / HPT_SHARDS));
     }
     if (sc.use_tlas || sc.n_mesh_instances > 0)
-    hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries, mode), st, sc, n, org, dir, hit, hit_inst, stack_entries, mode == LDS_TLAS ? 1 : 0,
+    hipLaunchKernelGGL(k_scene_closest, dim3(grid), dim3(HPT_BLOCK), trav_lds_bytes(stack_entries, mode, false, tlas_meshes(sc)), st, sc, n, org, dir, hit, hit_inst, stack_entries, (mode == LDS_TLAS ? 1 : 0) | (tlas_meshes(sc) ? 2 : 0),
                        (const uint2*)mq, (const uint32_t*)mq_count, (uint32_t)(hptk_mq_slots((uint64_t)n) / HPT_SHARDS));
     hipLaunchKernelGGL(k_scene_hitinfo, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, node, prim, t, side, pos, normal, uvw);
 }
@@ -1714,7 +1853,7 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     HptkPlan p;
     p.extend_entries = carve_entries(stack_entries, sc.use_tlas != 0);
     p.extend_mode = scene_lds_mode(p.extend_entries, sc);
-    p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode, extend_stk16(sc));
+    p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode, extend_stk16(sc) || tlas_stk16(sc), tlas_meshes(sc));
     p.extend_per_cu = extend_resident(sc, p.extend_mode == LDS_TLAS, p.extend_lds);
     p.analytic_per_cu = resident_blocks(k_extend_a<false>, 0);
     p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);

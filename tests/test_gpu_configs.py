@@ -92,6 +92,30 @@ def test_tlas_equals_linear(ctx, olib, desc, monkeypatch):
     lin.close(); tl.close()
 
 
+def test_two_level_kernel_variants_agree(ctx, olib, desc, monkeypatch):
+    """the forms of the two-level kernel a scene with mesh instances can run -- 16-bit stack with packed leaf codes (default when
+    they fit), 32-bit stack, deferred triangle tests (HPT_TLAS_TRI_DEFER=1, the round-3 A/B variant) -- give identical hit
+    records and identical images"""
+    import hpt
+    d = scenes.instanced(desc.meshes[0], 3)        # 27 teapot instances + floor
+    o, dd = camera_and_random_rays(ol.OracleScene(olib, d), d, 6000, 3)
+    out = []
+    for env in ({}, {"HPT_TLAS_STK16": "0"}, {"HPT_TLAS_TRI_DEFER": "1"}):
+        for k in ("HPT_TLAS_STK16", "HPT_TLAS_TRI_DEFER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sc = hpt.Scene(ctx, d, host_bvh=host_tree)
+        assert sc.info().uses_tlas
+        out.append((sc.intersect(o, dd), sc.render(spp=3, max_depth=5, seed=4)))
+        sc.close()
+    for h, img in out[1:]:
+        for k in ("node", "prim", "t", "side", "pos", "normal"):
+            np.testing.assert_array_equal(h[k], out[0][0][k])
+        np.testing.assert_array_equal(img["rgb"], out[0][1]["rgb"])
+        assert img["stats"].rays_bounce == out[0][1]["stats"].rays_bounce
+
+
 def test_node32_equals_node64(ctx, olib, desc, monkeypatch):
     """16-bit quantised child boxes (Node32, default for trees that do not fit L2) against float boxes (Node64): boxes
     only grow, so every hit record is identical -- mesh-local parity rays on the teapot (host tree), and a TLAS scene"""
