@@ -26,7 +26,8 @@ b = json.load(open(src + "/pmc_fetch.json"))
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --inflight 1 --steps 1 --warmup 0 --cpu-spp 0 --no-alt" +
                   (" --spp 64" if config == "teapot" else " --config %s --spp %s" % (config, b["config"]["workload"].split(" spp")[0].split()[-1])),
        "config": config, "workload": b["config"]["workload"],
-       "unit": "KB per launch as rocprofv3 reports; bytes = KB*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B reads at 64 B)",
+       "unit": "KB per launch as rocprofv3 reports; bytes = KB*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B line requests at 64 B -- "
+               "checked for random 32-B and 64-B gathers too: profiles/r03c_fetch_size_gather.txt, one 64-B tally per missed record, 128 B moved)",
        "rays_per_launch": b["rays_per_step"] / b["roofline"]["launches"],
        "source_sha256": source_sha256(), "source_files": list(STAMPED)}
 # the un-instrumented k_extend variant of this scene (template arguments differ by scene: node format, TLAS, work counter)
