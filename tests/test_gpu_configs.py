@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+from mismatch import classify_node_mismatches
 import scenes
 from conftest import host_tree
 
@@ -32,7 +33,7 @@ def check_scene(ctx, olib, desc, n_rays, spp, depth, host_bvh=None, img_tol=2e-3
     same_node = g["node"] == r["node"]
     # equal-t ties between different objects are resolved by node order on both sides; inside a mesh the tie winner
     # depends on the tree (edge rays, excluded by north_star): compare ids where t differs from every neighbour
-    assert same_node.mean() > 0.9999, same_node.mean()
+    classify_node_mismatches(desc, o, d, g, r, max_frac=1e-4)      # each one proven a reference AABB false miss (tests/mismatch.py), else it fails
     np.testing.assert_array_equal(g["t"][same_node], r["t"][same_node])
     np.testing.assert_array_equal(g["side"][same_node], r["side"][same_node])
     same_prim = same_node & (g["prim"] == r["prim"])

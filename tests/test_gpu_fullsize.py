@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+from mismatch import classify_node_mismatches
 import scenes
 from conftest import host_tree
 from test_gpu_configs import camera_and_random_rays
@@ -21,7 +22,10 @@ def hits_against_oracle(gsc, osc, desc, n_rays, seed):
     o, d = camera_and_random_rays(osc, desc, n_rays, seed)
     g = gsc.intersect(o, d); r = osc.intersect(o, d)
     same_node = g["node"] == r["node"]
-    assert same_node.mean() > 0.9995, same_node.mean()
+    # every disagreement must be a hit the reference's own (non-conservative) AABB tests cull although its exact primitive test
+    # hits: proven ray by ray with the box-free restatement (tests/mismatch.py); anything else fails
+    n_false_miss = classify_node_mismatches(desc, o, d, g, r)
+    print("%d rays, %d reference AABB false misses" % (len(o), n_false_miss))
     assert (r["node"] >= 0).mean() > 0.2
     np.testing.assert_array_equal(g["t"][same_node], r["t"][same_node])
     np.testing.assert_array_equal(g["side"][same_node], r["side"][same_node])

@@ -79,3 +79,26 @@ def test_primary_rays_and_radiance_64x48_1spp(oscene, olib, desc):
     assert close.all(axis=1).mean() >= 0.995, close.all(axis=1).mean()
     assert ref.sum() > 0 and (ref.max(axis=1) > 0).mean() > 0.05      # (1 spp: a path has to find the light)
     np.testing.assert_allclose(mine.mean(axis=0), ref.mean(axis=0), rtol=2e-2)
+
+
+def test_mismatch_classifier_reproduces_exact_hits(oscene, desc):
+    """tests/mismatch.py (the judge of GPU / oracle node disagreements in the -m gpu tests): its box-free exact test gives the oracle's t
+    bit for bit on rays where nothing is in doubt, and the classifier rejects a fabricated disagreement"""
+    import pytest
+    import mismatch
+    o, d = _scene_rays(oscene, desc, 120, 11)
+    r = oscene.intersect(o, d)
+    hit = np.flatnonzero(r["node"] >= 0)[:60]
+    assert len(hit) >= 40 and len(set(r["node"][hit])) >= 3
+    for i in hit:
+        assert np.float32(mismatch._exact_t(desc, int(r["node"][i]), o[i], d[i])) == r["t"][i]
+    assert mismatch.classify_node_mismatches(desc, o, d, r, r) == 0
+    fake = {k: v.copy() for k, v in r.items() if isinstance(v, np.ndarray)}
+    i = hit[0]
+    fake["node"][i] = -1                                            # "the GPU misses where the oracle hits"
+    with pytest.raises(AssertionError, match="the GPU misses"):
+        mismatch.classify_node_mismatches(desc, o, d, fake, r)
+    fake["node"][i] = r["node"][i]; fake["t"][i] = r["t"][i] * np.float32(0.5)
+    fake["node"][i] = [n for n in set(r["node"][hit]) if n != r["node"][i]][0]      # "another node, nearer": the exact test does not reproduce it
+    with pytest.raises(AssertionError):
+        mismatch.classify_node_mismatches(desc, o, d, fake, r)
