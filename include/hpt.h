@@ -80,10 +80,18 @@ typedef struct {
 
 enum {
     HPT_RENDER_COUNTERS = 1u,      /* run the instrumented extend kernel: fills nodes_visited / tris_tested / inst_tests */
-    HPT_RENDER_TIME_KERNELS = 2u   /* bracket every kernel with HIP events on the context stream; fills seconds_*.  Runs the
+    HPT_RENDER_TIME_KERNELS = 2u,  /* bracket every kernel with HIP events on the context stream; fills seconds_*.  Runs the
                                       passes one after the other on that stream (without the flag a render keeps two
                                       wavefront passes in flight, the second on a stream of the library's own, joined
                                       back into the context stream before the call's work ends; same results bit for bit) */
+    HPT_RENDER_EXACT_SHADE = 4u    /* shade with the reference's own f32 operations (IEEE divide and square root, libm-style
+                                      sincosf / cosf(asinf z): scene.rs:211-225, 394-429) instead of the default 1-ulp forms
+                                      (v_rcp / v_rsq, a quadrant polynomial for sin/cos of 2 pi r, sqrt(1 - z^2)).  Hits are
+                                      decided by exact arithmetic either way; this flag only concerns the bounce.  The default
+                                      differs from it by a few ulp per bounce direction -- inside the image-RMSE contract, and
+                                      what the ~0.003 % of paths whose roulette / lobe / hit decision sits within that distance
+                                      do differently.  With the flag, path lengths equal the CPU oracle's one for one (the
+                                      parity tests use it); the shade kernel is ~10 % slower. */
 };
 
 /* replaces the constants of main.rs:27-32 and the loop bounds of main.rs:67-107 */
@@ -237,7 +245,7 @@ int hpt_render_device(hpt_scene* scene, const hpt_render_params* params, float* 
  * GPU shares that GPU's one array (whatever the context or scene): calls that overlap on one GPU race -- serialise them. */
 #define HPT_NOALLOC_MAX_PIXELS (1u << 19)
 #define HPT_NOALLOC_MAX_SPP 4096
-#define HPT_NOALLOC_SCRATCH_MB 124
+#define HPT_NOALLOC_SCRATCH_MB 127
 int hpt_render_device_noalloc(hpt_scene* scene, const hpt_render_params* params, float* rgb_sum_device,
                               hpt_render_stats* stats);
 /* Samples first_sample+1 ..= first_sample+spp (params: adaptive = 0) of the listed pixels ADDED to a caller-held

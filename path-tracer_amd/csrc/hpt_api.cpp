@@ -110,6 +110,7 @@ struct hpt_scene {
     int n_xf = 0, n_mat = 0;
     HptkPlan plan;              // launch configuration of this scene's kernels (hpt_scene_commit)
     int shade_grid = 0;         // k_shade workgroups per launch
+    bool fuse_analytic = false; // k_shade of depth d runs the analytic stage of depth d + 1 (instance-list path; set at commit)
     int analytic_grid = 0;      // k_extend_a workgroups per launch
     int32_t tlas_nodes = 0, node_bytes = 64, trees_optimized = 0; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
@@ -681,7 +682,11 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     // launch configuration: depends on the committed scene only (occupancy queries, LDS layout) -- not per launch
     hptk_plan(s->stack_entries, d, s->n_xf, s->n_mat, &s->plan);
     // k_shade: two rounds of exactly the resident workgroups (5/CU -> 10/CU measured best: 8/CU +3 %, 4/CU +8 %)
-    s->shade_grid = s->plan.shade_per_cu > 0 ? ctx->num_cus * s->plan.shade_per_cu * 2 : ctx->max_blocks;
+    // instance-list path: k_shade of depth d also runs the analytic stage of depth d + 1 (k_extend_a is then launched for depth 0 only);
+    // HPT_FUSE_ANALYTIC=0 at commit keeps the two kernels apart (A/B)
+    { const char* e = getenv("HPT_FUSE_ANALYTIC"); s->fuse_analytic = !use_tlas && !(e && atoi(e) == 0); }
+    const int shade_per_cu = s->fuse_analytic ? s->plan.shade_fused_per_cu : s->plan.shade_per_cu;
+    s->shade_grid = shade_per_cu > 0 ? ctx->num_cus * shade_per_cu * 2 : ctx->max_blocks;
     if (const char* e = getenv("HPT_SHADE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) s->shade_grid = ctx->num_cus * v; }
     s->analytic_grid = s->plan.analytic_per_cu > 0 ? ctx->num_cus * s->plan.analytic_per_cu * 2 : ctx->max_blocks;      // (4 / 8 / 16 per CU with two passes in flight: 13.47 / 13.62 / 14.05 Grays/s)
     if (const char* e = getenv("HPT_ANALYTIC_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) s->analytic_grid = ctx->num_cus * v; }
@@ -898,10 +903,10 @@ static int run_pass(hpt_scene* s, DPass& ps, long long* accum, float* minmax, bo
     const int ablocks = (int)std::min<uint64_t>(std::min<uint64_t>(chunks, std::max<uint64_t>(chunks / 32, (uint64_t)ctx->num_cus * 4)), (uint64_t)s->analytic_grid);
     for (int depth = 0; depth <= ps.max_depth; ++depth) {
         if (!s->ds.use_tlas) {      // instance-list path: analytic stage over every ray, then the traversal over the rays that entered a mesh box
-            CHK(ev.begin(4, st)); hptk_extend_analytic(st, ablocks, s->ds, ps, depth, counters); CHK(ev.end(st));
+            if (depth == 0 || !s->fuse_analytic) { CHK(ev.begin(4, st)); hptk_extend_analytic(st, ablocks, s->ds, ps, depth, counters); CHK(ev.end(st)); }      // (fused: k_shade of depth - 1 did it)
             if (s->ds.n_mesh_instances > 0) { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
         } else { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
-        CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->plan, s->ds, ps, depth, s->n_xf, s->n_mat); CHK(ev.end(st));
+        CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->plan, s->ds, ps, depth, s->n_xf, s->n_mat, s->fuse_analytic && ps.hit_par != 0, counters, (ps.flags & HPT_RENDER_EXACT_SHADE) != 0); CHK(ev.end(st));
     }
     if (after) HIPCHK(hipStreamWaitEvent(st, after, 0));
     CHK(ev.begin(3, st)); hptk_resolve(st, ctx->max_blocks, ps, accum, minmax); CHK(ev.end(st));
@@ -922,7 +927,9 @@ static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps, int 
     DevBuf &hit = set ? s->x[set - 1].hit : s->w_hit, &hit_inst = set ? s->x[set - 1].hit_inst : s->w_hit_inst, &mq = set ? s->x[set - 1].mq : s->w_mq,
            &radiance = set ? s->x[set - 1].radiance : s->w_radiance, &counts = set ? s->x[set - 1].counts : s->w_counts;
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) CHK(q[a][k].ensure(max_paths * 16));
-    CHK(hit.ensure(max_paths * 16)); CHK(hit_inst.ensure(max_paths * 4)); CHK(radiance.ensure(max_paths * 16));
+    const uint64_t hit_sets = s->fuse_analytic ? 2 : 1;      // fused shade + analytic stage: hit records of even and odd depths apart
+    CHK(hit.ensure(hit_sets * max_paths * 16)); CHK(hit_inst.ensure(hit_sets * max_paths * 4)); CHK(radiance.ensure(max_paths * 16));
+    ps.hit_par = s->fuse_analytic ? (uint32_t)max_paths : 0u;
     if (!s->ds.use_tlas && s->ds.n_mesh_instances > 0) CHK(mq.ensure(max_paths * 48));      // mesh queue of the instance-list path: items, origins, directions
     CHK(counts.ensure((size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
@@ -988,7 +995,7 @@ static int render_range(hpt_scene* s, const hpt_render_params* p, const uint32_t
         DPass& ps = psv[set];
         ps.halton = s->w_halton.as<float2>() + done;
         ps.pixel_list = pixel_list; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
-        ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
+        ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth; ps.flags = p->flags;
         ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
         const int rc = run_pass(s, ps, accum, minmax, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s, inflight), set ? ctx->aux_stream[set - 1] : st,
                                 inflight > 1 && passes > 0 ? ctx->ev_done[(set + inflight - 1) % inflight] : nullptr, inflight > 1 ? ctx->ev_done[set] : nullptr);
@@ -1090,6 +1097,7 @@ extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* 
     ps.hit = (float4*)(base + HPT_NOALLOC_OFF_HIT); ps.radiance = (float4*)(base + HPT_NOALLOC_OFF_RADIANCE);
     ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.mq = (uint4*)(base + HPT_NOALLOC_OFF_MQ); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
     ps.stat = (unsigned long long*)(base + HPT_NOALLOC_OFF_STAT);
+    ps.hit_par = s->fuse_analytic ? (uint32_t)HPT_NOALLOC_SLOTS : 0u;
     float2* d_halton = (float2*)(base + HPT_NOALLOC_OFF_HALTON);
     long long* d_accum = (long long*)(base + HPT_NOALLOC_OFF_ACCUM);
     // the array keeps the last call's contents: statistics and the accumulator start at zero here, counters and radiance per pass (run_pass)
@@ -1105,7 +1113,7 @@ extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* 
         const int cur = std::min(S, p->spp - done);
         ps.halton = d_halton + done;
         ps.pixel_list = nullptr; ps.n_slots = (uint32_t)npix; ps.S = (uint32_t)cur;
-        ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth;
+        ps.first_sample = (uint32_t)(p->first_sample + done); ps.seed = p->seed; ps.max_depth = p->max_depth; ps.flags = p->flags;
         ps.shard_cap = shard_cap_for(npix * (uint64_t)cur);
         if ((uint64_t)ps.shard_cap * HPT_SHARDS > HPT_NOALLOC_SLOTS) return fail(HPT_ERR_LIMIT, "hpt_render_device_noalloc: pass of %llu paths does not fit the static workspace", (unsigned long long)(npix * (uint64_t)cur));
         CHK(run_pass(s, ps, d_accum, nullptr, (p->flags & HPT_RENDER_COUNTERS) != 0, ev, extend_grid(s, 1), st, nullptr, nullptr));

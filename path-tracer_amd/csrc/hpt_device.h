@@ -58,13 +58,13 @@
 // queue slots: 64 segments, each rounded up to whole 256-path chunks
 #define HPT_NOALLOC_SLOTS ((size_t)HPT_NOALLOC_MAX_PATHS + (size_t)HPT_SHARDS * HPT_BLOCK)
 #define HPT_ALIGN256(x) (((size_t)(x) + 255) & ~(size_t)255)
-// regions, each 256-B aligned: 6 queue arrays + hit + radiance (16 B per slot), hit_inst (4 B), mesh queue (3 x 16 B), counters, statistics, Halton,
+// regions, each 256-B aligned: 6 queue arrays + 2 x hit + radiance (16 B per slot), 2 x hit_inst (4 B), mesh queue (3 x 16 B), counters, statistics, Halton,
 // the radiance accumulator of the call (32 B per pixel)
 #define HPT_NOALLOC_OFF_Q(k) ((size_t)(k) * HPT_ALIGN256(HPT_NOALLOC_SLOTS * 16))
-#define HPT_NOALLOC_OFF_HIT HPT_NOALLOC_OFF_Q(6)
-#define HPT_NOALLOC_OFF_RADIANCE HPT_NOALLOC_OFF_Q(7)
-#define HPT_NOALLOC_OFF_HIT_INST HPT_NOALLOC_OFF_Q(8)
-#define HPT_NOALLOC_OFF_MQ (HPT_NOALLOC_OFF_HIT_INST + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 4))
+#define HPT_NOALLOC_OFF_HIT HPT_NOALLOC_OFF_Q(6)            // two arrays (even / odd depths: DPass.hit_par = HPT_NOALLOC_SLOTS)
+#define HPT_NOALLOC_OFF_RADIANCE HPT_NOALLOC_OFF_Q(8)
+#define HPT_NOALLOC_OFF_HIT_INST HPT_NOALLOC_OFF_Q(9)       // two arrays as well
+#define HPT_NOALLOC_OFF_MQ (HPT_NOALLOC_OFF_HIT_INST + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 8))
 #define HPT_NOALLOC_OFF_COUNTS (HPT_NOALLOC_OFF_MQ + HPT_ALIGN256(HPT_NOALLOC_SLOTS * 48))
 #define HPT_NOALLOC_OFF_STAT (HPT_NOALLOC_OFF_COUNTS + HPT_ALIGN256((size_t)HPT_COUNTS_TOTAL * 4))
 #define HPT_NOALLOC_OFF_HALTON (HPT_NOALLOC_OFF_STAT + 256)
@@ -158,6 +158,8 @@ struct DPass {
     DQueue q[2];
     float4* hit;         // (t, u, v, as_float(global tri or -1))
     uint32_t* hit_inst;  // instance | side<<31, HPT_MISS_INST on miss
+    uint32_t hit_par;    // records between the hit / hit_inst arrays of even and odd depths (fused shade + analytic stage: k_shade of depth d writes
+                         // the analytic results of depth d + 1 while depth d's records are still read); 0: one array for every depth
     uint4* mq;           // mesh queue of the current depth, sharded like the path queues: for every ray that entered a mesh box the item
                          // (slot, first mesh instance to visit, best analytic t, its instance | side), then -- HPT_SHARDS * shard_cap records
                          // further on each -- the ray's origin and direction (48 B per slot; see block_analytic)
@@ -171,5 +173,6 @@ struct DPass {
     uint32_t first_sample;       // Halton index of sample s is first_sample + s + 1
     uint32_t seed;
     int32_t max_depth;
+    uint32_t flags;              // HPT_RENDER_* of the call (k_shade launch: HPT_RENDER_EXACT_SHADE)
     unsigned long long* stat;    // [0] rays, [1] nodes, [2] tris, [3] inst tests, [4] primary rays, [5] rays that entered a mesh box
 };

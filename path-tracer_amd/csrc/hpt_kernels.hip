@@ -73,6 +73,15 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
 }
 // cgmath normalize: v * (1 / |v|)
 __device__ __forceinline__ f3 normalize3(f3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
+// Shading-side arithmetic (k_shade<.., FAST>, the default; HPT_RENDER_EXACT_SHADE selects FAST = false): the image contract is an RMSE,
+// not bits, so directions are normalised with
+// v_rsq_f32 and quotients taken with v_rcp_f32 (1 ulp each) instead of the IEEE expansions (sqrt + divide: ~25 instructions).
+template <bool FAST> __device__ __forceinline__ f3 normalize_t(f3 a) {
+    if constexpr (FAST) return scale3(a, __builtin_amdgcn_rsqf(dot3(a, a))); else return normalize3(a);
+}
+template <bool FAST> __device__ __forceinline__ float quot_t(float a, float b) {
+    if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b); else return a / b;
+}
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 __device__ __forceinline__ f3 xyz(float4 q) { return mk3(q.x, q.y, q.z); }
 // row-dot of a float4 row (xyz) with v in cgmath order
@@ -451,11 +460,31 @@ __device__ __forceinline__ bool analytic_phase(const DScene& sc, f3 o, f3 d, uin
 // hit_inst[slot], ray_o[slot] and ray_d[slot] -- four divergent pulls that each fetched a 64-B sector for 4..16 bytes and sat
 // behind the item load (r02e: 229 B of physical traffic per walked ray, most of k_extend's).  Thin items (slot, first mesh
 // instance) stay for the test entries.
+// the rays of one wave that entered a mesh box go to segment seg of the mesh queue: ballot + wave prefix + one atomic per wave
+template <bool FAT>
+__device__ __forceinline__ void mesh_queue_append(bool queued, uint32_t seg, uint2 item, const Hit& a, f3 mlo, f3 mld, void* __restrict__ mq,
+                                                  uint32_t* __restrict__ mq_counts, uint32_t mq_shards, uint32_t mq_cap, unsigned& n_queued) {
+    const unsigned long long mask = __ballot(queued);
+    if (mask) {
+        const unsigned lane = threadIdx.x & 63u;
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&mq_counts[seg * HPT_COUNT_STRIDE], (uint32_t)__popcll(mask));
+        wbase = __shfl(wbase, 0);
+        if (queued) {
+            const uint32_t e = seg * mq_cap + wbase + lane_prefix(mask);
+            if constexpr (FAT) {
+                const uint32_t n = mq_shards * mq_cap;
+                ((uint4*)mq)[e] = make_uint4(item.x, item.y, __float_as_uint(a.t), a.inst_side);
+                ((float4*)mq)[n + e] = make_float4(mlo.x, mlo.y, mlo.z, 0.0f); ((float4*)mq)[2u * n + e] = make_float4(mld.x, mld.y, mld.z, 0.0f);
+            } else ((uint2*)mq)[e] = item;
+        }
+        if (lane == 0) n_queued += (unsigned)__popcll(mask);
+    }
+}
 template <bool COUNT, bool FAT = false>
 __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView& wv, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                float4* __restrict__ hit, uint32_t* __restrict__ hit_inst, void* __restrict__ mq,
                                                uint32_t* __restrict__ mq_counts, uint32_t mq_shards, uint32_t mq_cap, unsigned& n_inst, unsigned& n_queued) {
-    const unsigned lane = threadIdx.x & 63u;
     const uint32_t total = input_pieces(wv) / (HPT_BLOCK / 64);      // 256-slot chunks up to the fullest segment
     for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
         uint32_t i;
@@ -470,21 +499,7 @@ __device__ __forceinline__ void block_analytic(const DScene& sc, const WorkView&
             queued = analytic_phase<COUNT>(sc, xyz(o4), xyz(d4), i, a, item, n_inst, mlo, mld);
             hit[i] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); hit_inst[i] = a.inst_side;   // final for unqueued rays, interim otherwise
         }
-        const unsigned long long mask = __ballot(queued);
-        if (mask) {
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&mq_counts[seg * HPT_COUNT_STRIDE], (uint32_t)__popcll(mask));
-            wbase = __shfl(wbase, 0);
-            if (queued) {
-                const uint32_t e = seg * mq_cap + wbase + lane_prefix(mask);
-                if constexpr (FAT) {
-                    const uint32_t n = mq_shards * mq_cap;
-                    ((uint4*)mq)[e] = make_uint4(item.x, item.y, __float_as_uint(a.t), a.inst_side);
-                    ((float4*)mq)[n + e] = make_float4(mlo.x, mlo.y, mlo.z, 0.0f); ((float4*)mq)[2u * n + e] = make_float4(mld.x, mld.y, mld.z, 0.0f);
-                } else ((uint2*)mq)[e] = item;
-            }
-            if (lane == 0) n_queued += (unsigned)__popcll(mask);
-        }
+        mesh_queue_append<FAT>(queued, seg, item, a, mlo, mld, mq, mq_counts, mq_shards, mq_cap, n_queued);
     }
 }
 
@@ -1242,10 +1257,11 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
         __syncthreads();
     }
 #endif
-    if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true, MESHES, STK16>(sc, L, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+    float4* hit = ps.hit + (size_t)(depth & 1) * ps.hit_par; uint32_t* hit_inst = ps.hit_inst + (size_t)(depth & 1) * ps.hit_par;
+    if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true, MESHES, STK16>(sc, L, wv, q.ray_o, q.ray_d, hit, hit_inst, n_int, n_tri, n_inst);
     else {
         wv.counts = ps.counts + HPT_MQ_COUNTS(depth);      // instance-list path: the input is the mesh queue k_extend_a filled
-        block_closest_hit<COUNT, NODE32, false, DYN, STK16, true>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, n_int, n_tri, n_inst);
+        block_closest_hit<COUNT, NODE32, false, DYN, STK16, true>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, hit, hit_inst, n_int, n_tri, n_inst);
     }
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
@@ -1261,7 +1277,8 @@ k_extend_a(DScene sc, DPass ps, int depth) {
     const DQueue& q = ps.q[depth & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.work = nullptr;
     unsigned n_inst = 0, n_queued = 0;
-    block_analytic<COUNT, true>(sc, wv, q.ray_o, q.ray_d, ps.hit, ps.hit_inst, ps.mq, ps.counts + HPT_MQ_COUNTS(depth), HPT_SHARDS, ps.shard_cap, n_inst, n_queued);
+    block_analytic<COUNT, true>(sc, wv, q.ray_o, q.ray_d, ps.hit + (size_t)(depth & 1) * ps.hit_par, ps.hit_inst + (size_t)(depth & 1) * ps.hit_par, ps.mq,
+                                ps.counts + HPT_MQ_COUNTS(depth), HPT_SHARDS, ps.shard_cap, n_inst, n_queued);
     const unsigned long long nq = wave_sum<unsigned long long>(n_queued);
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&ps.stat[5], nq);
     if (COUNT) {
@@ -1324,35 +1341,59 @@ __device__ __forceinline__ f3 texture_sample_environment(const DScene& sc, const
     return texture_sample(sc, tx, mk3(0.5f + atan2f(dir.y, dir.x) / (2.0f * PI_F), 0.5f - asinf(-dir.z) / PI_F, 0.0f));
 }
 // scene.rs:211-213
+template <bool FAST = false>
 __device__ __forceinline__ f3 reflect_ray(f3 vec, f3 normal) {
-    return normalize3(add3(neg3(vec), scale3(normal, 2.0f * dot3(normal, vec))));
+    return normalize_t<FAST>(add3(neg3(vec), scale3(normal, 2.0f * dot3(normal, vec))));
 }
 // scene.rs:215-225
+template <bool FAST = false>
 __device__ __forceinline__ bool refract_ray(f3 vec, f3 normal, float n1, float n2, f3& out) {
-    float n = n1 / n2;
+    float n = quot_t<FAST>(n1, n2);
     float ndv = dot3(normal, vec);
     f3 s = scale3(sub3(scale3(normal, ndv), vec), n);
     float cos_sqr = 1.0f - (n * n) * (1.0f - ndv * ndv);
-    if (cos_sqr >= 0.0f) { out = normalize3(sub3(s, scale3(normal, sqrtf(cos_sqr)))); return true; }
+    if (cos_sqr >= 0.0f) { out = normalize_t<FAST>(sub3(s, scale3(normal, FAST ? __builtin_amdgcn_sqrtf(cos_sqr) : sqrtf(cos_sqr)))); return true; }
     return false;
 }
+template <bool FAST = false>
 __device__ __forceinline__ void smallest_axis_basis(f3 vec, f3& u, f3& v) {   // scene.rs:395-404
     float xa = fabsf(vec.x), ya = fabsf(vec.y), za = fabsf(vec.z);
     f3 axis;
     if (xa < ya && xa < za) axis = mk3(1, 0, 0);
     else if (ya < za) axis = mk3(0, 1, 0);
     else axis = mk3(0, 0, 1);
-    u = normalize3(cross3(vec, axis));
-    v = normalize3(cross3(vec, u));
+    u = normalize_t<FAST>(cross3(vec, axis));
+    v = normalize_t<FAST>(cross3(vec, u));
 }
 // scene.rs:394-411 (max_angle) / 413-429 (hemisphere: z_min = 0 exactly)
+// sin and cos of 2 pi r for r in [0, 1): the quadrant comes off r exactly (r * 4 and r - q / 4 are exact in f32), the remainder
+// |x| <= pi / 4 goes through the degree-7 / degree-8 minimax polynomials of the Cephes single-precision kernels (error below 1 ulp of
+// the result on that range).  ocml's sincosf(theta) spends most of its ~90 instructions on a range reduction this argument never needs.
+__device__ __forceinline__ void sincos_turns(float r, float& s, float& c) {
+    const float q = rintf(r * 4.0f);
+    const float x = fmaf(q, -0.25f, r) * (2.0f * PI_F);
+    const float x2 = x * x;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, x2, 8.3321608736e-3f), x2, -1.6666654611e-1f), x2 * x, x);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, x2, -1.388731625493765e-3f), x2, 4.166664568298827e-2f), x2 * x2, fmaf(-0.5f, x2, 1.0f));
+    const int k = (int)q;
+    const float a = (k & 1) ? cp : sp, b = (k & 1) ? sp : cp;      // quadrant 1, 3: (sin, cos) = (+-cos x, -+sin x)
+    s = (k & 2) ? -a : a;                                          // quadrants 2, 3: sin < 0 side
+    c = ((k + 1) & 2) ? -b : b;                                    // quadrants 1, 2: cos < 0 side
+}
+template <bool FAST = false>
 __device__ __forceinline__ f3 sample_about(f3 vec, float z, float r1) {
-    f3 u, v; smallest_axis_basis(vec, u, v);
-    float theta = r1 * 2.0f * PI_F;
-    float st, ct;
-    sincosf(theta, &st, &ct);
-    f3 o = add3(scale3(vec, z), scale3(add3(scale3(u, ct), scale3(v, st)), cosf(asinf(z))));
-    return normalize3(o);
+    f3 u, v; smallest_axis_basis<FAST>(vec, u, v);
+    float st, ct, rad;
+    if constexpr (FAST) {
+        sincos_turns(r1, st, ct);
+        rad = __builtin_amdgcn_sqrtf(fmaxf((1.0f - z) * (1.0f + z), 0.0f));      // cos(asin z) = sqrt(1 - z^2), without the cancellation near z = 1
+    } else {
+        float theta = r1 * 2.0f * PI_F;
+        sincosf(theta, &st, &ct);
+        rad = cosf(asinf(z));
+    }
+    f3 o = add3(scale3(vec, z), scale3(add3(scale3(u, ct), scale3(v, st)), rad));
+    return normalize_t<FAST>(o);
 }
 
 struct WorldHit { f3 pos, normal, uv; int side; int material; int node_id; int prim_local; };
@@ -1366,6 +1407,7 @@ __device__ __forceinline__ Tables global_tables(const DScene& sc) { Tables T; T.
 
 // need_uv = false skips the sphere's lat-long uv (atan2f + asinf, geometry.rs:61-64) when no texture of the hit
 // material reads it (all Blank: scene.rs:313 ignores the point) -- the result of the shade is unchanged.
+template <bool FAST = false>
 __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T, f3 o, f3 d, float t, float bu, float bv, int prim, uint32_t inst_side, bool need_uv) {
     WorldHit w;
     const DInstance& in = T.inst[inst_side & 0x7fffffffu];
@@ -1382,7 +1424,7 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
         pos = add3(lo, scale3(ld, t));
     }
     if (in.geom == 1) {
-        normal = normalize3(pos);
+        normal = normalize_t<FAST>(pos);
         uv = mk3(0, 0, 0);
         if (need_uv) uv = mk3(0.5f + atan2f(normal.y, normal.x) / (2.0f * PI_F), 0.5f - asinf(-normal.z) / PI_F, 0.0f);
     } else if (in.geom == 2) {
@@ -1400,7 +1442,7 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
     for (int k = in.xf_count - 1; k >= 0; --k) {
         const DXformFwd& X = T.xfwd[in.xf_first + k];
         pos = mk3(rowdot(X.m0, pos) + X.m0[3], rowdot(X.m1, pos) + X.m1[3], rowdot(X.m2, pos) + X.m2[3]);
-        normal = normalize3(mk3(rowdot(X.n0, normal), rowdot(X.n1, normal), rowdot(X.n2, normal)));
+        normal = normalize_t<FAST>(mk3(rowdot(X.n0, normal), rowdot(X.n1, normal), rowdot(X.n2, normal)));
     }
     w.pos = pos; w.normal = normal; w.uv = uv;
     return w;
@@ -1465,7 +1507,12 @@ k_scene_hitinfo(DScene sc, long long n, const float4* __restrict__ org, const fl
 // ------------------------------------------------------------------------------------------------ k_shade
 // One bounce of Scene::cast (scene.rs:130-188) in forward (throughput) form + append of the surviving paths to the
 // next queue.  radiance[path] += throughput * emission replaces the recursion's `color = emission + f * next`.
-template <bool LDS_SCENE>
+// FUSE (instance-list path): the analytic stage of the NEXT depth runs here, on the new ray while it is still in registers --
+// k_extend_a of depths 1.. is gone, and with it a 32-B read per ray and a launch per depth; its arithmetic (VALU-bound on its own:
+// ~600 instructions per ray) overlaps the queue traffic this kernel waits on.  The analytic result of slot dst goes to the hit
+// records of the other parity (this depth's are still being read by other waves), the rays that enter a mesh box to the mesh
+// queue of depth + 1.
+template <bool LDS_SCENE, bool FUSE = false, bool COUNT = false, bool FAST = true>
 __global__ void __launch_bounds__(HPT_BLOCK) HPT_SHADE_OCC
 k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
     Tables T;
@@ -1490,6 +1537,9 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
     const DQueue& qo = ps.q[(depth + 1) & 1];
     WorkView wv; wv.counts = ps.counts + (size_t)depth * HPT_COUNTS_PER_DEPTH; wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.work = nullptr;
     uint32_t* counts_out = ps.counts + (size_t)(depth + 1) * HPT_COUNTS_PER_DEPTH;
+    const float4* __restrict__ hit_in = ps.hit + (size_t)(depth & 1) * ps.hit_par;
+    const uint32_t* __restrict__ hit_inst_in = ps.hit_inst + (size_t)(depth & 1) * ps.hit_par;
+    unsigned n_inst = 0, n_queued = 0;
     const int lane = threadIdx.x & 63;
     const uint32_t total = work_items(wv);
     for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
@@ -1500,8 +1550,8 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
         float4 no = make_float4(0, 0, 0, 0), nd = make_float4(0, 0, 0, 0), nthr = make_float4(0, 0, 0, 0);
         if (valid) {
             const float4 o4 = qi.ray_o[i], d4 = qi.ray_d[i], thr4 = qi.thr[i];
-            const float4 h4 = ps.hit[i];
-            const uint32_t inst_side = ps.hit_inst[i];
+            const float4 h4 = hit_in[i];
+            const uint32_t inst_side = hit_inst_in[i];
             const uint32_t path = __float_as_uint(d4.w);
             const f3 o = xyz(o4), d = xyz(d4), thr = xyz(thr4);
             const float weight = o4.w;
@@ -1526,7 +1576,7 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
             } else {
                 const DMaterial& mat = T.mats[T.inst[inst_side & 0x7fffffffu].material];
                 const bool need_uv = (mat.diffuse.kind | mat.reflection.kind | mat.refraction.kind) != 0;
-                const WorldHit w = world_hit(sc, T, o, d, h4.x, h4.y, h4.z, __float_as_int(h4.w), inst_side, need_uv);
+                const WorldHit w = world_hit<FAST>(sc, T, o, d, h4.x, h4.y, h4.z, __float_as_int(h4.w), inst_side, need_uv);
                 const f3 diffuse = texture_sample(sc, mat.diffuse, w.uv);
                 const f3 reflection = texture_sample(sc, mat.reflection, w.uv);
                 const f3 refraction = texture_sample(sc, mat.refraction, w.uv);
@@ -1537,9 +1587,9 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                 float c1 = 1.0f - dot3(normal, neg3(d));
                 float c2 = c1 * c1;
                 const float ar = r0 + (1.0f - r0) * (c2 * c2 * c1);
-                float p_diffuse = (diffuse.x + diffuse.y + diffuse.z) / 3.0f;
-                float p_refraction = (1.0f - ar) * (refraction.x + refraction.y + refraction.z) / 3.0f;
-                float p_reflection = (1.0f + ar) * (reflection.x + reflection.y + reflection.z) / 3.0f;   // sic (scene.rs:154)
+                float p_diffuse = quot_t<FAST>(diffuse.x + diffuse.y + diffuse.z, 3.0f);
+                float p_refraction = quot_t<FAST>((1.0f - ar) * (refraction.x + refraction.y + refraction.z), 3.0f);
+                float p_reflection = quot_t<FAST>((1.0f + ar) * (reflection.x + reflection.y + reflection.z), 3.0f);   // sic (scene.rs:154)
                 const float p_range = p_diffuse + p_reflection + p_refraction;
                 const f3 emission = ld3(mat.emission);
                 if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f) { add = mul3(thr, emission); have_add = true; }
@@ -1547,9 +1597,9 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                     const RngKey key = rng_key(ps.seed, pixel, ps.first_sample + s + 1);
                     const uint32_t d0 = 2u + 4u * (uint32_t)depth;
                     if (!(rng_f32(key, d0) > weight)) {    // Russian roulette, no compensation (scene.rs:161)
-                        p_diffuse = p_diffuse / p_range;
-                        p_reflection = p_reflection / p_range;
-                        p_refraction = p_refraction / p_range;
+                        p_diffuse = quot_t<FAST>(p_diffuse, p_range);
+                        p_reflection = quot_t<FAST>(p_reflection, p_range);
+                        p_refraction = quot_t<FAST>(p_refraction, p_range);
                         const float rnd = rng_f32(key, d0 + 1);
                         const float ra = rng_f32(key, d0 + 2), rb = rng_f32(key, d0 + 3);
                         // the three lobes only choose (axis, z); the expensive cone sample (sincosf, asinf, three
@@ -1559,21 +1609,21 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
                             albedo = diffuse; p = p_diffuse;                       // scene.rs:413-429: hemisphere, z_min = 0
                         } else if (rnd < p_diffuse + p_reflection) {
                             const float z_min = mat.cos_refl_gloss;
-                            axis = reflect_ray(neg3(d), normal); z = z_min + ra * (1.0f - z_min);
+                            axis = reflect_ray<FAST>(neg3(d), normal); z = z_min + ra * (1.0f - z_min);
                             albedo = reflection; p = p_reflection;
                         } else if (rnd < p_diffuse + p_reflection + p_refraction) {
                             f3 rd;
-                            if (!refract_ray(neg3(d), normal, n1, n2, rd)) rd = reflect_ray(neg3(d), normal);
+                            if (!refract_ray<FAST>(neg3(d), normal, n1, n2, rd)) rd = reflect_ray<FAST>(neg3(d), normal);
                             const float z_min = mat.cos_refr_gloss;
                             axis = rd; z = z_min + ra * (1.0f - z_min);
                             albedo = refraction; p = p_refraction;
                         } else picked = false;
                         f3 new_dir = mk3(0, 0, 0);
-                        if (picked) new_dir = sample_about(axis, z, rb);
+                        if (picked) new_dir = sample_about<FAST>(axis, z, rb);
                         if (picked) {
                             const float ndot = dot3(normal, new_dir);
                             // f = n.dot(new_dir) * albedo / p   (scene.rs:172,176,180)
-                            const f3 f = divs3(scale3(albedo, ndot), p);
+                            const f3 f = FAST ? scale3(albedo, ndot * __builtin_amdgcn_rcpf(p)) : divs3(scale3(albedo, ndot), p);
                             const f3 nt = mul3(thr, f);
                             const f3 np = add3(w.pos, scale3(new_dir, 0.01f));   // BIAS scene.rs:122
                             no = make_float4(np.x, np.y, np.z, weight * p);
@@ -1596,10 +1646,31 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
             uint32_t wbase = 0;
             if (lane == 0) wbase = atomicAdd(&counts_out[seg * HPT_COUNT_STRIDE], (uint32_t)__popcll(mask));   // survivors stay in their segment
             wbase = __shfl(wbase, 0);
+            uint32_t dst = 0;
             if (alive) {
-                const uint32_t dst = seg * ps.shard_cap + wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                dst = seg * ps.shard_cap + wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                 qo.ray_o[dst] = no; qo.ray_d[dst] = nd; qo.thr[dst] = nthr;
             }
+            if constexpr (FUSE) {
+                bool queued = false;
+                uint2 item = make_uint2(0, 0);
+                f3 mlo = mk3(0, 0, 0), mld = mk3(0, 0, 1);
+                Hit a; a.t = HPT_INF; a.inst_side = HPT_MISS_INST;
+                if (alive) {
+                    queued = analytic_phase<COUNT>(sc, mk3(no.x, no.y, no.z), mk3(nd.x, nd.y, nd.z), dst, a, item, n_inst, mlo, mld);
+                    const size_t e = (size_t)((depth + 1) & 1) * ps.hit_par + dst;
+                    ps.hit[e] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); ps.hit_inst[e] = a.inst_side;
+                }
+                mesh_queue_append<true>(queued, seg, item, a, mlo, mld, ps.mq, ps.counts + HPT_MQ_COUNTS(depth + 1), HPT_SHARDS, ps.shard_cap, n_queued);
+            }
+        }
+    }
+    if constexpr (FUSE) {
+        const unsigned long long nq = wave_sum<unsigned long long>(n_queued);
+        if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&ps.stat[5], nq);
+        if (COUNT) {
+            const unsigned long long c = wave_sum<unsigned long long>(n_inst);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&ps.stat[3], c);
         }
     }
 }
@@ -1861,6 +1932,7 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     // resident workgroups of k_shade per CU (0: query failed); the pass launches a multiple of it -- work is strided
     // statically over the grid, so a grid of 1.6 x the resident workgroups runs one full round and one at 60 %
     p.shade_per_cu = p.shade_lds ? resident_blocks(k_shade<true>, p.shade_tables) : resident_blocks(k_shade<false>, 0);
+    p.shade_fused_per_cu = p.shade_lds ? resident_blocks(k_shade<true, true, false>, p.shade_tables) : resident_blocks(k_shade<false, true, false>, 0);
     *out = p;
 }
 static int g_refill = 24;
@@ -1874,9 +1946,15 @@ void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene&
     auto k = count ? extend_kernel<true>(sc, plan.extend_mode == LDS_TLAS) : extend_kernel<false>(sc, plan.extend_mode == LDS_TLAS);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(HPT_BLOCK), plan.extend_lds, st, sc, ps, depth, plan.extend_entries, g_refill);
 }
-void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat) {
-    if (plan.shade_lds) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(HPT_BLOCK), plan.shade_tables, st, sc, ps, depth, n_xf, n_mat);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth, n_xf, n_mat);
+template <bool FAST>
+static void launch_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat, bool fuse, bool count) {
+    auto k = plan.shade_lds ? (fuse ? (count ? k_shade<true, true, true, FAST> : k_shade<true, true, false, FAST>) : k_shade<true, false, false, FAST>)
+                            : (fuse ? (count ? k_shade<false, true, true, FAST> : k_shade<false, true, false, FAST>) : k_shade<false, false, false, FAST>);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(HPT_BLOCK), plan.shade_lds ? plan.shade_tables : 0, st, sc, ps, depth, n_xf, n_mat);
+}
+void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat, bool fuse, bool count, bool exact) {
+    if (exact) launch_shade<false>(st, blocks, plan, sc, ps, depth, n_xf, n_mat, fuse, count);      // HPT_RENDER_EXACT_SHADE
+    else launch_shade<true>(st, blocks, plan, sc, ps, depth, n_xf, n_mat, fuse, count);
 }
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, long long* accum, float* minmax) {
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(ps.n_slots, max_blocks)), dim3(HPT_BLOCK), 0, st, ps, accum, minmax);
@@ -1915,7 +1993,7 @@ void hptk_accum_resolve(hipStream_t st, int max_blocks, const long long* accum, 
 // ------------------------------------------------------------------------------------------------ static workspace
 // The pass buffers of hpt_render_device_noalloc (include/hpt.h): wavefront queues, hit records, radiance records, append
 // counters, statistics, Halton table for a frame of up to HPT_NOALLOC_MAX_PATHS pixels -- HPT_NOALLOC_SCRATCH_BYTES
-// (115 MB) of device memory that every GPU the library runs on holds from the first load of this code object to the end
+// (126 MB) of device memory that every GPU the library runs on holds from the first load of this code object to the end
 // of the process.  The array's NAME is a host-side stand-in, not a device address: host code gets each device's copy
 // through hipGetSymbolAddress (once per device, with that device current) and uses that pointer -- for kernel arguments,
 // hipMemsetAsync and copies alike.  The kernels take the pointer as an argument, exactly as they take the hipMalloc'ed

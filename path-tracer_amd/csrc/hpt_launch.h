@@ -14,13 +14,13 @@ struct HptkPlan {          // what hptk_plan derives from a committed scene (see
     int extend_entries = 1, extend_mode = 0, extend_per_cu = 0;   // stack entries carved, LDS layout, resident workgroups per CU (0: query failed)
     size_t extend_lds = 0;
     int analytic_per_cu = 0;                                      // resident workgroups per CU of k_extend_a
-    size_t shade_tables = 0; bool shade_lds = false; int shade_per_cu = 0;
+    size_t shade_tables = 0; bool shade_lds = false; int shade_per_cu = 0, shade_fused_per_cu = 0;   // (fused: k_shade + the next depth's analytic stage)
 };
 void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPlan* out);
 // instance-list scenes: analytic stage of a depth (every ray; fills the mesh queue), then hptk_extend over the mesh queue
 void hptk_extend_analytic(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, bool count);
 void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, bool count);
-void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat);
+void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat, bool fuse, bool count, bool exact);
 void hptk_halton(hipStream_t st, float2* out, uint32_t first_sample, uint32_t n);      // out[k] = halton(first_sample + k + 1, 2 | 3)
 void hptk_resolve(hipStream_t st, int max_blocks, const DPass& ps, long long* accum, float* minmax);
 void hptk_finish_pass(hipStream_t st, const DPass& ps);

@@ -18,7 +18,7 @@ I32P = C.POINTER(C.c_int32)
 U8P = C.POINTER(C.c_uint8)
 
 GEOM_NONE, GEOM_SPHERE, GEOM_PLANE, GEOM_MESH = 0, 1, 2, 3
-RENDER_COUNTERS, RENDER_TIME_KERNELS = 1, 2
+RENDER_COUNTERS, RENDER_TIME_KERNELS, RENDER_EXACT_SHADE = 1, 2, 4
 
 
 class BvhNode(C.Structure):

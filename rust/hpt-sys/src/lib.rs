@@ -23,6 +23,7 @@ pub const HPT_TEX_CHECKER: i32 = 1;
 pub const HPT_TEX_IMAGE: i32 = 2;
 pub const HPT_RENDER_COUNTERS: u32 = 1;
 pub const HPT_RENDER_TIME_KERNELS: u32 = 2;
+pub const HPT_RENDER_EXACT_SHADE: u32 = 4;
 
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct hpt_bvh_node { pub left: i32, pub right: i32, pub prim: i32, pub p1: [f32; 3], pub p2: [f32; 3] }
