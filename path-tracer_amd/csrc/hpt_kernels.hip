@@ -1366,12 +1366,14 @@ __device__ __forceinline__ void smallest_axis_basis(f3 vec, f3& u, f3& v) {   //
     v = normalize_t<FAST>(cross3(vec, u));
 }
 // scene.rs:394-411 (max_angle) / 413-429 (hemisphere: z_min = 0 exactly)
-// sin and cos of 2 pi r for r in [0, 1): the quadrant comes off r exactly (r * 4 and r - q / 4 are exact in f32), the remainder
-// |x| <= pi / 4 goes through the degree-7 / degree-8 minimax polynomials of the Cephes single-precision kernels (error below 1 ulp of
-// the result on that range).  ocml's sincosf(theta) spends most of its ~90 instructions on a range reduction this argument never needs.
+// sin and cos of theta = fl(fl(r * 2) * pi), the f32 angle scene.rs:409 forms from r in [0, 1) (the angle's own rounding, up to 4e-7, is
+// part of the reference's result, so it is kept): quadrant k = rint(theta * 2 / pi), remainder by a two-step Cody-Waite subtraction of
+// k * pi / 2 (|x| <= pi / 4 + 1e-7, exact to ~1e-8), then the degree-7 / degree-8 minimax polynomials of the Cephes single-precision
+// kernels (below 1 ulp on that range).  ocml's sincosf spends most of its ~90 instructions on a range reduction this argument never needs.
 __device__ __forceinline__ void sincos_turns(float r, float& s, float& c) {
-    const float q = rintf(r * 4.0f);
-    const float x = fmaf(q, -0.25f, r) * (2.0f * PI_F);
+    const float theta = r * 2.0f * PI_F;
+    const float q = rintf(theta * 0.63661977236758134f);
+    const float x = fmaf(q, -7.5497894158615964e-8f, fmaf(q, -1.5707962512969971f, theta));      // pi / 2 = 1.5707962512969971 + 7.5497894e-8
     const float x2 = x * x;
     const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, x2, 8.3321608736e-3f), x2, -1.6666654611e-1f), x2 * x, x);
     const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, x2, -1.388731625493765e-3f), x2, 4.166664568298827e-2f), x2 * x2, fmaf(-0.5f, x2, 1.0f));
