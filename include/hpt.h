@@ -159,7 +159,7 @@ int hpt_device_count(void);
 /* Counter-based generator that replaces rand::random::<f32>() (main.rs:76-77, scene.rs:161,169,407,408,425,426).
  *   mix(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
  *   k1 = mix(pixel + mix(seed));  k2 = mix(sample ^ 0x5bd1e995 ^ seed*0x9E3779B9)
- *   u  = (mix(k1 ^ mix(k2 + dim*0x9E3779B9)) >> 8) * 2^-24           in [0,1)
+ *   u  = (mix(k1 ^ (k2 + dim*0x9E3779B9)) >> 8) * 2^-24                in [0,1)   (one hash per number on top of the two key hashes)
  * pixel = y*W+x, sample = Halton index (1-based), dim: 0,1 lens; 2+4*depth+{0 roulette,1 lobe,2 z,3 theta}. */
 float hpt_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim);
 float hpt_halton(int32_t index, int32_t base);                                   /* scene.rs:431 */

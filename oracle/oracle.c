@@ -109,7 +109,7 @@ float orc_halton(int32_t index, int32_t base) {
 /* Counter-based generator replacing rand::random::<f32>() (rand 0.3: 24-bit uniform in [0,1)).
  * Spec (shared with include/hpt.h, restated here on purpose so the checker stays independent):
  *   mix = lowbias32; k1 = mix(pixel + mix(seed)); k2 = mix(sample ^ 0x5bd1e995 ^ k-seed)
- *   u   = mix(k1 ^ mix(k2 + dim * 0x9E3779B9)) >> 8, scaled by 2^-24 */
+ *   u   = mix(k1 ^ (k2 + dim * 0x9E3779B9)) >> 8, scaled by 2^-24 */
 static inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
@@ -117,7 +117,7 @@ static inline uint32_t mix32(uint32_t x) {
 float orc_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
     uint32_t k1 = mix32(pixel + mix32(seed));
     uint32_t k2 = mix32(sample ^ 0x5bd1e995U ^ (seed * 0x9E3779B9U));
-    uint32_t h = mix32(k1 ^ mix32(k2 + dim * 0x9E3779B9U));
+    uint32_t h = mix32(k1 ^ (k2 + dim * 0x9E3779B9U));
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 

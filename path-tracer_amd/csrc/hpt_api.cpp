@@ -156,7 +156,7 @@ static inline uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= 
 extern "C" float hpt_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
     const uint32_t k1 = mix32(pixel + mix32(seed));
     const uint32_t k2 = mix32(sample ^ 0x5bd1e995U ^ (seed * 0x9E3779B9U));
-    const uint32_t h = mix32(k1 ^ mix32(k2 + dim * 0x9E3779B9U));
+    const uint32_t h = mix32(k1 ^ (k2 + dim * 0x9E3779B9U));
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 extern "C" float hpt_halton(int32_t index, int32_t base) {   // scene.rs:431-443

@@ -104,7 +104,7 @@ __device__ __forceinline__ RngKey rng_key(uint32_t seed, uint32_t pixel, uint32_
     return k;
 }
 __device__ __forceinline__ float rng_f32(RngKey k, uint32_t dim) {
-    uint32_t h = mix32(k.k1 ^ mix32(k.k2 + dim * 0x9E3779B9U));
+    uint32_t h = mix32(k.k1 ^ (k.k2 + dim * 0x9E3779B9U));      // ONE hash per number: the keys are hashed already (rounds 1-3a hashed k2 + dim * phi as well: 10 -> 6 hashes per bounce)
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 

@@ -241,7 +241,7 @@ def rng(seed, pixel, sample, dim):
         seed = np.uint32(seed); pixel = np.asarray(pixel, np.uint32); sample = np.asarray(sample, np.uint32)
         k1 = _mix(pixel + _mix(np.array([seed], np.uint32))[0])
         k2 = _mix(sample ^ np.uint32(0x5bd1e995) ^ np.uint32((int(seed) * 0x9E3779B9) & 0xffffffff))
-        h = _mix(k1 ^ _mix(k2 + np.uint32((dim * 0x9E3779B9) & 0xffffffff)))
+        h = _mix(k1 ^ (k2 + np.uint32((dim * 0x9E3779B9) & 0xffffffff)))
     return ((h >> np.uint32(8)).astype(F) * F(1.0 / 16777216.0)).astype(F)
 
 

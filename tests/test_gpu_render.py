@@ -211,7 +211,8 @@ def _adaptive_rounds_body(ctx, olib, d, sc, ref, stream):
         acc, mm, _ = eng.new_buffers(8)
         first = 0
         for cnt in split:
-            sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), plist.data_ptr(), len(plist), spp=cnt, first_sample=first, max_depth=4, seed=3)
+            sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), plist.data_ptr(), len(plist), spp=cnt, first_sample=first, max_depth=4, seed=3,
+                                   flags=hpt.RENDER_EXACT_SHADE)      # (the reference's own bounce arithmetic for the oracle comparisons below)
             first += cnt
         torch.cuda.synchronize()
         bufs.append((acc.cpu().numpy(), mm.cpu().numpy()))
@@ -226,12 +227,12 @@ def _adaptive_rounds_body(ctx, olib, d, sc, ref, stream):
     np.testing.assert_allclose(bufs[0][0][touched, :3] / 2.0 ** 24, want, rtol=1e-5, atol=1e-6)
     # ... and of the GPU's OWN samples bit for bit (tests/accum_ref.py restates the accumulator), resolved like the library does on the host
     import accum_ref
-    own = sc.render_samples(spp=8, max_depth=4, seed=3)
+    own = sc.render_samples(spp=8, max_depth=4, seed=3, flags=hpt.RENDER_EXACT_SHADE)
     mine = accum_ref.accumulate(np.zeros((npix, 4), dtype=np.int64), own[touched], rows=np.flatnonzero(touched))
     np.testing.assert_array_equal(bufs[0][0], mine)
     np.testing.assert_array_equal(hpt.accum_resolve(mine, num_samples=8), accum_ref.resolve(mine, num_samples=8))
-    np.testing.assert_allclose(bufs[0][1][touched, :3], per[touched].min(axis=1), rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(bufs[0][1][touched, 3:], per[touched].max(axis=1), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(bufs[0][1][touched, :3], per[touched].min(axis=1), rtol=2e-5, atol=1e-6)      # (libm vs ocml sin / cos / asin: a few ulp per bounce)
+    np.testing.assert_allclose(bufs[0][1][touched, 3:], per[touched].max(axis=1), rtol=2e-5, atol=1e-6)
     acc, mm, _ = eng.new_buffers(8)
     with pytest.raises(hpt.HptError):
         sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), 0, 0, spp=4, adaptive=True)
