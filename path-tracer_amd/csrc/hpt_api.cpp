@@ -103,7 +103,7 @@ struct hpt_scene {
     uint64_t generation = 0;    // stamp of the last commit, unique in the process (a group re-replicates its clones when the stamp of
                                 // the scene it is handed differs -- a re-commit, or ANOTHER scene that the allocator put at the same address)
     // device side
-    DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_meshinst, d_xinv, d_xfwd, d_materials, d_images, d_pool;
+    DevBuf d_nodes, d_tris, d_trishade, d_meshes, d_instances, d_meshinst, d_xinv, d_xfwd, d_materials, d_images, d_pool, d_pnormal;
     std::vector<DMesh> h_meshes;
     DScene ds;
     int stack_entries = 1;
@@ -270,7 +270,7 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (hipStream_t a : s->ctx->aux_stream) if (a) (void)hipStreamSynchronize(a);   // (joined already unless a render failed half way)
-    DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_materials,
+    DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_pnormal, &s->d_materials,
                      &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_mq, &s->t_mq, &s->t_mqcount, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
                      &s->w_accum, &s->w_minmax, &s->w_spp, &s->w_list[0], &s->w_list[1], &s->w_listcount, &s->w_out,
                      &s->t_org, &s->t_dir, &s->t_hit, &s->t_side};
@@ -659,12 +659,28 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     CHK(upload(s->d_tris, tris, st)); CHK(upload(s->d_trishade, trishade, st));
     CHK(upload(s->d_meshes, s->h_meshes, st)); CHK(upload(s->d_instances, inst, st)); CHK(upload(s->d_meshinst, meshinst, st));
     CHK(upload(s->d_xinv, xinv, st)); CHK(upload(s->d_xfwd, xfwd, st));
+    // world-space normal of every plane instance: (0, 0, 1) carried out through the chain with the f32 operations of world_hit (scene.rs:286
+    // per level: Minv^T n, normalised) -- the default shade reads it instead of redoing the chain per hit
+    std::vector<float> pnormal(inst.size() * 4, 0.0f);
+    for (size_t i = 0; i < inst.size(); ++i) {
+        if (inst[i].geom != HPT_GEOM_PLANE) continue;
+        float n[3] = {0.0f, 0.0f, 1.0f};
+        for (int k = inst[i].xf_count - 1; k >= 0; --k) {
+            const DXformFwd& X = xfwd[inst[i].xf_first + k];
+            const float a = (X.n0[0] * n[0] + X.n0[1] * n[1]) + X.n0[2] * n[2], b = (X.n1[0] * n[0] + X.n1[1] * n[1]) + X.n1[2] * n[2],
+                        c = (X.n2[0] * n[0] + X.n2[1] * n[1]) + X.n2[2] * n[2];
+            const float inv = 1.0f / std::sqrt((a * a + b * b) + c * c);
+            n[0] = a * inv; n[1] = b * inv; n[2] = c * inv;
+        }
+        for (int k = 0; k < 3; ++k) pnormal[4 * i + k] = n[k];
+    }
+    CHK(upload(s->d_pnormal, pnormal, st));
     CHK(upload(s->d_materials, mats, st)); CHK(upload(s->d_images, imgs, st)); CHK(upload(s->d_pool, pool, st));
     HIPCHK(hipStreamSynchronize(st));   // the staging vectors die at scope end
     DScene& d = s->ds;
     d.nodes = s->d_nodes.as<float4>(); d.tris = s->d_tris.as<float4>(); d.trishade = s->d_trishade.as<float4>();
     d.meshes = s->d_meshes.as<DMesh>(); d.instances = s->d_instances.as<DInstance>(); d.mesh_instances = s->d_meshinst.as<int32_t>();
-    d.xinv = s->d_xinv.as<DXformInv>(); d.xfwd = s->d_xfwd.as<DXformFwd>();
+    d.xinv = s->d_xinv.as<DXformInv>(); d.xfwd = s->d_xfwd.as<DXformFwd>(); d.plane_normal = s->d_pnormal.as<float4>();
     d.materials = s->d_materials.as<DMaterial>(); d.images = s->d_images.as<DImage>(); d.image_pool = s->d_pool.as<uint8_t>();
     d.n_instances = (int32_t)inst.size(); d.n_meshes = (int32_t)s->h_meshes.size();
     s->n_xf = (int)xinv.size(); s->n_mat = (int)mats.size();

@@ -130,6 +130,7 @@ struct DScene {
     const int32_t* mesh_instances;   // indices (into instances[]) of the mesh instances, ascending
     const DXformInv* xinv;
     const DXformFwd* xfwd;
+    const float4* plane_normal;      // per instance: world-space normal of a plane instance (0 otherwise); hpt_scene_commit
     const DMaterial* materials;
     const DImage* images;
     const uint8_t* image_pool;

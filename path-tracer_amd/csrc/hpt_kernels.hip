@@ -1404,8 +1404,8 @@ struct WorldHit { f3 pos, normal, uv; int side; int material; int node_id; int p
 // (scene.rs:263-271): geometry.rs:57-65 sphere, :79-85 plane, :147-153 mesh.
 // The per-instance tables world_hit / k_shade read per lane (divergent addresses).  k_shade stages them in LDS when the
 // scene is small (LDS_SCENE): an LDS read costs ~64 cycles instead of an L2 round trip per dependent hop.
-struct Tables { const DInstance* inst; const DXformInv* xinv; const DXformFwd* xfwd; const DMaterial* mats; };
-__device__ __forceinline__ Tables global_tables(const DScene& sc) { Tables T; T.inst = sc.instances; T.xinv = sc.xinv; T.xfwd = sc.xfwd; T.mats = sc.materials; return T; }
+struct Tables { const DInstance* inst; const DXformInv* xinv; const DXformFwd* xfwd; const DMaterial* mats; const float* pnormal; };      // pnormal: 4 floats per instance
+__device__ __forceinline__ Tables global_tables(const DScene& sc) { Tables T; T.inst = sc.instances; T.xinv = sc.xinv; T.xfwd = sc.xfwd; T.mats = sc.materials; T.pnormal = (const float*)sc.plane_normal; return T; }
 
 // need_uv = false skips the sphere's lat-long uv (atan2f + asinf, geometry.rs:61-64) when no texture of the hit
 // material reads it (all Blank: scene.rs:313 ignores the point) -- the result of the shade is unchanged.
@@ -1444,8 +1444,12 @@ __device__ __forceinline__ WorldHit world_hit(const DScene& sc, const Tables& T,
     for (int k = in.xf_count - 1; k >= 0; --k) {
         const DXformFwd& X = T.xfwd[in.xf_first + k];
         pos = mk3(rowdot(X.m0, pos) + X.m0[3], rowdot(X.m1, pos) + X.m1[3], rowdot(X.m2, pos) + X.m2[3]);
+        if (FAST && in.geom == 2) continue;      // a plane's world normal is a per-instance constant (DScene.plane_normal, below)
         normal = normalize_t<FAST>(mk3(rowdot(X.n0, normal), rowdot(X.n1, normal), rowdot(X.n2, normal)));
     }
+    // (the hit POINT keeps the reference's operations in either mode: the next ray starts 0.01 off the surface along a direction that may
+    //  graze it, and a point 4e-6 elsewhere -- o + t d instead of the chain -- starts 5e-4 of the paths on the other side: measured)
+    if (FAST && in.geom == 2) normal = ld3(T.pnormal + 4u * (inst_side & 0x7fffffffu));
     w.pos = pos; w.normal = normal; w.uv = uv;
     return w;
 }
@@ -1524,14 +1528,16 @@ k_shade(DScene sc, DPass ps, int depth, int n_xf, int n_mat) {
         DXformInv* lxi = (DXformInv*)(li + sc.n_instances);
         DXformFwd* lxf = (DXformFwd*)(lxi + n_xf);
         DMaterial* lm = (DMaterial*)(lxf + n_xf);
+        float* lpn = (float*)(lm + n_mat);
         const int wi = sc.n_instances * (int)(sizeof(DInstance) / 4), wxi = n_xf * (int)(sizeof(DXformInv) / 4),
                   wxf = n_xf * (int)(sizeof(DXformFwd) / 4), wm = n_mat * (int)(sizeof(DMaterial) / 4);
         for (int j = threadIdx.x; j < wi; j += HPT_BLOCK) ((uint32_t*)li)[j] = ((const uint32_t*)sc.instances)[j];
         for (int j = threadIdx.x; j < wxi; j += HPT_BLOCK) ((uint32_t*)lxi)[j] = ((const uint32_t*)sc.xinv)[j];
         for (int j = threadIdx.x; j < wxf; j += HPT_BLOCK) ((uint32_t*)lxf)[j] = ((const uint32_t*)sc.xfwd)[j];
         for (int j = threadIdx.x; j < wm; j += HPT_BLOCK) ((uint32_t*)lm)[j] = ((const uint32_t*)sc.materials)[j];
+        for (int j = threadIdx.x; j < 4 * sc.n_instances; j += HPT_BLOCK) lpn[j] = ((const float*)sc.plane_normal)[j];
         __syncthreads();
-        T.inst = li; T.xinv = lxi; T.xfwd = lxf; T.mats = lm;
+        T.inst = li; T.xinv = lxi; T.xfwd = lxf; T.mats = lm; T.pnormal = lpn;
     } else {
         T = global_tables(sc);
     }
@@ -1929,7 +1935,8 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode, extend_stk16(sc) || tlas_stk16(sc), tlas_meshes(sc));
     p.extend_per_cu = extend_resident(sc, p.extend_mode == LDS_TLAS, p.extend_lds);
     p.analytic_per_cu = resident_blocks(k_extend_a<false>, 0);
-    p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial);
+    p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial) +
+                     (size_t)sc.n_instances * sizeof(float4);
     p.shade_lds = p.shade_tables <= 24 * 1024;
     // resident workgroups of k_shade per CU (0: query failed); the pass launches a multiple of it -- work is strided
     // statically over the grid, so a grid of 1.6 x the resident workgroups runs one full round and one at 60 %
