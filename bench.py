@@ -18,8 +18,9 @@ Inputs are resident in HBM before the timed region (the scene is committed once)
 The default N=1 run also carries "other_configs": configs[2] (1 M-triangle soup, 256 spp) and configs[4] (10 k spheres, 256 spp,
 depth 16) at their BASELINE sizes, one step each after the headline (--no-others skips them).
 
-Extra objects on the JSON line: "roofline" (k_extend, the BVH traversal kernel -- the analytic stage of the extend step,
-k_extend_a, is a launch of its own and shown as analytic_share_of_step: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak;
+Extra objects on the JSON line: "roofline" (k_extend, the BVH traversal kernel: algorithmic bytes / HIP-event kernel time vs the
+8 TB/s HBM peak.  The analytic stage of the extend step -- spheres, planes, mesh root boxes -- runs inside k_shade on the ray that
+kernel has just made, k_extend_a only at depth 0: analytic_share_of_step is that depth-0 launch, shade_share_of_step covers the rest;
 the event-bracketed launches are the same K steps run once more on ONE stream, right after the timed region: with two
 passes in flight the event interval of a launch would also cover the other pass's kernels sharing the GPU with it;
 `hbm_physical` / `valu` = the committed rocprofv3 counter passes of the same frame, flagged `stale` when they were

@@ -894,7 +894,9 @@ static int extend_grid(const hpt_scene* s, int inflight) {
             per_cu = std::min(4, (int)((160u * 1024u) / std::max<size_t>(s->plan.extend_lds, 1)));
         // (two-level kernel: one slot -- r03c, HPT_EXTEND_BLOCKS_PER_CU sweep with two passes in flight: 3 375 instanced teapots
         //  2 / 3 / 4 / 5 per CU of 5 resident = 2.86 / 3.17 / 3.21 / 3.11 Grays/s, 10 k spheres 2 / 3 / 4 of 4 = 4.19 / 4.27 / 4.15)
-        const int spare = ctx->extend_spare >= 0 ? ctx->extend_spare : (s->ds.use_tlas ? 1 : std::max(per_cu - 4, 0));
+        // (instance-list path: every resident slot since k_shade carries the analytic stage -- r03e, 1080p teapot, two passes in flight:
+        //  4 / 6 / 7 of 7 per CU = 17.97 / 18.45 / 18.49 Grays/s; r03b, with the analytic stage a kernel of its own, had 4 ahead; the soup does not care)
+        const int spare = ctx->extend_spare >= 0 ? ctx->extend_spare : (s->ds.use_tlas ? 1 : 0);
         if (inflight > 1 && per_cu > spare) per_cu -= spare;
     }
     return ctx->num_cus * std::max(1, per_cu);
