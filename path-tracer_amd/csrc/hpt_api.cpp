@@ -910,7 +910,8 @@ static int run_pass(hpt_scene* s, DPass& ps, long long* accum, float* minmax, bo
     hpt_context* ctx = s->ctx;
     HIPCHK(hipMemsetAsync(ps.counts, 0, (size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(ps.radiance, 0, (size_t)ps.n_slots * ps.S * sizeof(float4), st));
-    CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps); CHK(ev.end(st));
+    const bool fused = s->fuse_analytic && ps.hit_par != 0;      // raygen / k_shade run the analytic stage of the ray they make
+    CHK(ev.begin(0, st)); hptk_raygen(st, ctx->max_blocks, s->ds, ps, fused, counters); CHK(ev.end(st));
     const uint64_t n_paths = (uint64_t)ps.n_slots * ps.S;
     const int blocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)extend_blocks);
     const int sblocks = (int)std::min<uint64_t>((n_paths + HPT_BLOCK - 1) / HPT_BLOCK, (uint64_t)s->shade_grid);
@@ -921,10 +922,10 @@ static int run_pass(hpt_scene* s, DPass& ps, long long* accum, float* minmax, bo
     const int ablocks = (int)std::min<uint64_t>(std::min<uint64_t>(chunks, std::max<uint64_t>(chunks / 32, (uint64_t)ctx->num_cus * 4)), (uint64_t)s->analytic_grid);
     for (int depth = 0; depth <= ps.max_depth; ++depth) {
         if (!s->ds.use_tlas) {      // instance-list path: analytic stage over every ray, then the traversal over the rays that entered a mesh box
-            if (depth == 0 || !s->fuse_analytic) { CHK(ev.begin(4, st)); hptk_extend_analytic(st, ablocks, s->ds, ps, depth, counters); CHK(ev.end(st)); }      // (fused: k_shade of depth - 1 did it)
+            if (!fused) { CHK(ev.begin(4, st)); hptk_extend_analytic(st, ablocks, s->ds, ps, depth, counters); CHK(ev.end(st)); }      // (fused: k_raygen / k_shade of depth - 1 did it)
             if (s->ds.n_mesh_instances > 0) { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
         } else { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
-        CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->plan, s->ds, ps, depth, s->n_xf, s->n_mat, s->fuse_analytic && ps.hit_par != 0, counters, (ps.flags & HPT_RENDER_EXACT_SHADE) != 0); CHK(ev.end(st));
+        CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->plan, s->ds, ps, depth, s->n_xf, s->n_mat, fused, counters, (ps.flags & HPT_RENDER_EXACT_SHADE) != 0); CHK(ev.end(st));
     }
     if (after) HIPCHK(hipStreamWaitEvent(st, after, 0));
     CHK(ev.begin(3, st)); hptk_resolve(st, ctx->max_blocks, ps, accum, minmax); CHK(ev.end(st));

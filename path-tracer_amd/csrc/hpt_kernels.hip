@@ -1181,11 +1181,14 @@ k_trace_rays(DScene sc, int stack_entries, DMesh mesh, uint32_t n, const float4*
 
 // ------------------------------------------------------------------------------------------------ k_raygen
 // main.rs:65-85.  path = slot * S + s (queue order); slot -> pixel through pixel_list in adaptive passes.
+// FUSE (instance-list path): the analytic stage of depth 0 runs here on the camera ray (as k_shade does for the later depths).
+template <bool FUSE = false, bool COUNT = false>
 __global__ void __launch_bounds__(HPT_BLOCK)
 k_raygen(DScene sc, DPass ps) {
     const DCamera& c = sc.cam;
     const f3 a = ld3(c.a), right = ld3(c.right), up = ld3(c.up), cpos = ld3(c.pos);
     const uint32_t n = ps.n_slots * ps.S;
+    unsigned n_inst = 0, n_queued = 0;
     for (uint32_t path = blockIdx.x * HPT_BLOCK + threadIdx.x; path < n; path += gridDim.x * HPT_BLOCK) {
         const uint32_t slot = path / ps.S, s = path - slot * ps.S;
         const uint32_t pixel = ps.pixel_list ? ps.pixel_list[slot] : slot;
@@ -1206,6 +1209,22 @@ k_raygen(DScene sc, DPass ps) {
         ps.q[0].ray_o[q] = make_float4(eye.x, eye.y, eye.z, 1.0f);
         ps.q[0].ray_d[q] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(s * ps.n_slots + slot));   // its radiance record
         ps.q[0].thr[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel | (s << 26)));   // pixel < 2^26, s < 64
+        if constexpr (FUSE) {
+            uint2 item = make_uint2(0, 0);
+            f3 mlo = mk3(0, 0, 0), mld = mk3(0, 0, 1);
+            Hit a;
+            const bool queued = analytic_phase<COUNT>(sc, eye, dir, q, a, item, n_inst, mlo, mld);
+            ps.hit[q] = make_float4(a.t, 0.0f, 0.0f, __int_as_float(-1)); ps.hit_inst[q] = a.inst_side;      // depth 0: the even-depth records
+            mesh_queue_append<true>(queued, seg, item, a, mlo, mld, ps.mq, ps.counts + HPT_MQ_COUNTS(0), HPT_SHARDS, ps.shard_cap, n_queued);
+        }
+    }
+    if constexpr (FUSE) {
+        const unsigned long long nq = wave_sum<unsigned long long>(n_queued);
+        if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&ps.stat[5], nq);
+        if (COUNT) {
+            const unsigned long long c = wave_sum<unsigned long long>(n_inst);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&ps.stat[3], c);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < HPT_SHARDS) {
         // live entries of segment s at depth 0: its full chunks + (maybe) the globally last, partial chunk
@@ -1922,8 +1941,9 @@ void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, con
                        (const uint2*)mq, (const uint32_t*)mq_count, (uint32_t)(hptk_mq_slots((uint64_t)n) / HPT_SHARDS));
     hipLaunchKernelGGL(k_scene_hitinfo, dim3(grid), dim3(HPT_BLOCK), 0, st, sc, n, org, dir, hit, hit_inst, node, prim, t, side, pos, normal, uvw);
 }
-void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps) {
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
+void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps, bool fuse, bool count) {
+    auto k = fuse ? (count ? k_raygen<true, true> : k_raygen<true, false>) : k_raygen<false, false>;
+    hipLaunchKernelGGL(k, dim3(grid_for((uint64_t)ps.n_slots * ps.S, max_blocks)), dim3(HPT_BLOCK), 0, st, sc, ps);
 }
 // Everything about a scene's launches that depends only on the committed scene (LDS layout, kernel variant, resident
 // workgroups per CU): computed once by hpt_scene_commit -- the occupancy queries cost host time that would otherwise sit

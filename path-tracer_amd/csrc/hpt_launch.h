@@ -9,7 +9,7 @@ void hptk_trace_rays(hipStream_t st, int max_blocks, const DScene& sc, const DMe
 void hptk_scene_intersect(hipStream_t st, int max_blocks, int stack_entries, const DScene& sc, long long n, const float4* org,
                           const float4* dir, float4* hit, uint32_t* hit_inst, int* node, int* prim, float* t, uint8_t* side,
                           float4* pos, float4* normal, float4* uvw, uint2* mq, uint32_t* mq_count);
-void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps);
+void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& ps, bool fuse, bool count);
 struct HptkPlan {          // what hptk_plan derives from a committed scene (see hpt_kernels.hip)
     int extend_entries = 1, extend_mode = 0, extend_per_cu = 0;   // stack entries carved, LDS layout, resident workgroups per CU (0: query failed)
     size_t extend_lds = 0;
