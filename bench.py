@@ -293,6 +293,19 @@ def measure(args, scene, desc, tree, workload, base, world, rank, backend, strea
     else:
         bvh_text = ("TLAS over instances + " if info.uses_tlas else "") + ("reference bvh.rs BLAS built on host, restructured at flatten time" if tree else "library SAH")
     nominal = bool(info.device_bytes < 32 << 20)
+    # the other big kernel of the step: k_shade, which on instance-list scenes also runs the analytic stage of the ray it makes.  Its queue
+    # traffic per shaded ray: 68 B read (three 16-B path records, hit 16 B, hit_inst 4 B), per surviving path 48 B of path records + 20 B
+    # of analytic hit record written, per path that enters a mesh box a 48-B mesh-queue slot (scripts/micro/stream_state.hip: a kernel
+    # that only moves these bytes takes 23 ps per path)
+    survive = (rays_local - sum(s.rays_primary for s in stats)) / rays_local
+    shade_bytes_per_ray = 68.0 + survive * (48.0 + (20.0 + 48.0 * walked_frac if not info.uses_tlas else 0.0))
+    shade_valu = recorded_valu("k_shade", args.config) if default_frame else None
+    shade_stage = {"kernel": "k_shade" + ("" if info.uses_tlas else " (+ analytic stage of the next depth)"),
+                   "avg_launch_ms": round(shade_s_local / max(ext_launches, 1) * 1e3, 4), "bytes_per_ray": round(shade_bytes_per_ray, 1),
+                   "GB/s": round(shade_bytes_per_ray * rays_local / shade_s_local / 1e9, 1) if shade_s_local else None,
+                   "frac": round(shade_bytes_per_ray * rays_local / shade_s_local / HBM_PEAK, 4) if shade_s_local else None,
+                   "ps_per_ray": round(shade_s_local / rays_local * 1e12, 2) if shade_s_local else None, "valu": shade_valu,
+                   "limiter": ("valu_issue" if shade_valu["frac"] >= 0.7 else "hbm") if shade_valu else None}
     line = {
         "metric": "Mrays/sec (primary+bounce), %s" % ("teapot 1080p" if args.config == "teapot" else args.config), "value": round(rays_total / elapsed / 1e6, 2), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -324,7 +337,7 @@ def measure(args, scene, desc, tree, workload, base, world, rank, backend, strea
                          args.steps, serial_elapsed / args.steps * 1e3, args.inflight if args.inflight > 0 else 2),
                      "rays_walked_frac": round(walked_frac, 4),
                      "extend_share_of_step": round(ext_s_local / serial_elapsed, 3), "analytic_share_of_step": round(ana_s_local / serial_elapsed, 3),
-                     "shade_share_of_step": round(shade_s_local / serial_elapsed, 3),
+                     "shade_share_of_step": round(shade_s_local / serial_elapsed, 3), "shade_stage": shade_stage,
                      "source_sha256": tree_sha256()},
     }
     return line

@@ -31,7 +31,7 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- py
        "rays_per_launch": b["rays_per_step"] / b["roofline"]["launches"],
        "source_sha256": source_sha256(), "source_files": list(STAMPED)}
 # the un-instrumented k_extend variant of this scene (template arguments differ by scene: node format, TLAS, work counter)
-for key, name, optional in (("k_extend", "void k_extend<false,", False), ("k_extend_a", "void k_extend_a<false>", True), ("k_shade", "void k_shade<", False)):
+for key, name, optional in (("k_extend", "void k_extend<false,", False), ("k_extend_a", "void k_extend_a<false>", True), ("k_raygen", "void k_raygen<", True), ("k_shade", "void k_shade<", False)):
     f, n = grab(src + "/pmc_fetch_summary.txt", name, "FETCH_SIZE", optional)
     w, _ = grab(src + "/pmc_write_summary.txt", name, "WRITE_SIZE", optional)
     if f is None:

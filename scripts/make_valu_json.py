@@ -13,7 +13,7 @@ txt = open(src).read().split("\n")
 SIMDS, SES = 256 * 4, 32
 
 
-def block(prefix):
+def block(prefix, optional=False):
     out = {}
     for i, l in enumerate(txt):
         if l.startswith(prefix):
@@ -23,6 +23,8 @@ def block(prefix):
                     break
                 out[g.group(1)] = float(g.group(3)); out["launches"] = int(g.group(4))
             return out
+    if optional:
+        return None
     raise SystemExit("no %s in %s" % (prefix, src))
 
 
@@ -32,10 +34,13 @@ res = {"command": "rocprofv3 --pmc <8 SQ counters> -- python3 scripts/gpu_prof.p
        "source_sha256": source_sha256(), "source_files": list(STAMPED),
        "formula": "valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * SQ_BUSY_CYCLES / 32 shader engines); "
                   "valu_lane_util = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)"}
-kernels = (("k_extend", "void k_extend<false, false"), ("k_extend_a", "void k_extend_a<false>"), ("k_shade", "void k_shade<")) if config == "teapot" else \
-          (("k_extend", "void k_extend<false, "), ("k_shade", "void k_shade<"))
-for key, name in kernels:
-    b = block(name)
+# (instance-list scenes since r03e: the analytic stage runs inside k_raygen (depth 0) and k_shade (the later depths); k_extend_a only with HPT_FUSE_ANALYTIC=0)
+kernels = (("k_extend", "void k_extend<false, false", False), ("k_extend_a", "void k_extend_a<false>", True), ("k_raygen", "void k_raygen<", True), ("k_shade", "void k_shade<", False)) if config == "teapot" else \
+          (("k_extend", "void k_extend<false, ", False), ("k_shade", "void k_shade<", False))
+for key, name, optional in kernels:
+    b = block(name, optional)
+    if b is None:
+        continue
     cycles = b["SQ_BUSY_CYCLES"] / SES
     res[key] = {"launches": b["launches"], "valu_wave_insts_per_launch": b["SQ_INSTS_VALU"], "salu_wave_insts_per_launch": b["SQ_INSTS_SALU"],
                 "kernel_cycles": round(cycles), "valu_busy_frac": min(1.0, round(b["SQ_ACTIVE_INST_VALU"] * 4 / (SIMDS * cycles), 4)),

@@ -347,3 +347,36 @@ def test_passes_in_flight_do_not_change_results(ctx, desc):
     finally:
         ctx.set_passes_in_flight(2)
         gsc.close()
+
+
+def test_fused_analytic_stage_equals_separate_kernels(ctx, desc, monkeypatch):
+    """instance-list scenes: k_raygen / k_shade run the analytic stage of the ray they make (hit records per depth parity); the
+    separate k_extend_a launches (HPT_FUSE_ANALYTIC=0 at commit) must leave the same bits -- accumulators, per-pixel min/max,
+    ray and test counts -- in both shade modes, with ragged passes and a pixel list."""
+    import torch
+    import hpt
+    d = resized(desc, 80, 60)
+    npix = 80 * 60
+    plist = torch.arange(3, npix, 5, dtype=torch.int32, device="cuda")
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("HPT_FUSE_ANALYTIC", fuse)
+        sc = hpt.Scene(ctx, d, host_bvh=host_tree)
+        got = []
+        for flags in (0, hpt.RENDER_EXACT_SHADE):
+            acc = torch.zeros((npix, 4), dtype=torch.int64, device="cuda")
+            mm = torch.empty((npix, 6), dtype=torch.float32, device="cuda"); mm[:, :3] = float("inf"); mm[:, 3:] = 0.0
+            torch.cuda.synchronize()
+            st = sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), 0, npix, want_stats=True, spp=7, max_depth=8, seed=11, spp_per_pass=3,
+                                        flags=flags | hpt.RENDER_COUNTERS)
+            st2 = sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), plist.data_ptr(), len(plist), want_stats=True, spp=2, first_sample=7, max_depth=3, seed=11,
+                                         flags=flags)
+            torch.cuda.synchronize()
+            got.append((acc.cpu().numpy(), mm.cpu().numpy(), (st.rays_primary, st.rays_bounce, st.inst_tests, st.rays_mesh), (st2.rays_primary, st2.rays_bounce, st2.rays_mesh)))
+        res.append(got)
+        sc.close()
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2] and a[3] == b[3]
+    rays = res[0][0][2][0] + res[0][0][2][1]
+    assert int(res[0][0][0][:, :3].sum()) > 0 and 8 * rays <= res[0][0][2][2] <= 9 * rays      # every ray met the eight analytic instances (+ the mesh box)
