@@ -114,8 +114,8 @@ struct hpt_scene {
     int analytic_grid = 0;      // k_extend_a workgroups per launch
     int32_t tlas_nodes = 0, node_bytes = 64, trees_optimized = 0; int64_t n_tris_total = 0; uint64_t device_bytes = 0;
     // render workspace (grow-only, reused across calls: nothing is allocated in a steady-state render call)
-    DevBuf w_q[2][3], w_hit, w_hit_inst, w_mq, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
-    struct PassBufs { DevBuf q[2][3], hit, hit_inst, mq, radiance, counts; } x[HPT_MAX_INFLIGHT - 1];   // pass buffers of the further passes in flight
+    DevBuf w_q[2][3], w_hit, w_hit_inst, w_mq, w_mq_bin, w_radiance, w_counts, w_halton, w_stat, w_accum, w_minmax, w_spp, w_list[2], w_listcount, w_out;
+    struct PassBufs { DevBuf q[2][3], hit, hit_inst, mq, mq_bin, radiance, counts; } x[HPT_MAX_INFLIGHT - 1];   // pass buffers of the further passes in flight
     // trace workspace
     DevBuf t_org, t_dir, t_hit, t_side, t_misc[9], t_mq, t_mqcount;
 };
@@ -271,13 +271,13 @@ extern "C" void hpt_scene_destroy(hpt_scene* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     for (hipStream_t a : s->ctx->aux_stream) if (a) (void)hipStreamSynchronize(a);   // (joined already unless a render failed half way)
     DevBuf* all[] = {&s->d_nodes, &s->d_tris, &s->d_trishade, &s->d_meshes, &s->d_instances, &s->d_meshinst, &s->d_xinv, &s->d_xfwd, &s->d_pnormal, &s->d_materials,
-                     &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_mq, &s->t_mq, &s->t_mqcount, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
+                     &s->d_images, &s->d_pool, &s->w_hit, &s->w_hit_inst, &s->w_mq, &s->w_mq_bin, &s->t_mq, &s->t_mqcount, &s->w_radiance, &s->w_counts, &s->w_halton, &s->w_stat,
                      &s->w_accum, &s->w_minmax, &s->w_spp, &s->w_list[0], &s->w_list[1], &s->w_listcount, &s->w_out,
                      &s->t_org, &s->t_dir, &s->t_hit, &s->t_side};
     for (DevBuf* b : all) b->release();
     for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) s->w_q[a][k].release();
     for (auto& x : s->x) {
-        x.hit.release(); x.hit_inst.release(); x.mq.release(); x.radiance.release(); x.counts.release();
+        x.hit.release(); x.hit_inst.release(); x.mq.release(); x.mq_bin.release(); x.radiance.release(); x.counts.release();
         for (int a = 0; a < 2; ++a) for (int k = 0; k < 3; ++k) x.q[a][k].release();
     }
     for (DevBuf& b : s->t_misc) b.release();
@@ -923,7 +923,11 @@ static int run_pass(hpt_scene* s, DPass& ps, long long* accum, float* minmax, bo
     for (int depth = 0; depth <= ps.max_depth; ++depth) {
         if (!s->ds.use_tlas) {      // instance-list path: analytic stage over every ray, then the traversal over the rays that entered a mesh box
             if (!fused) { CHK(ev.begin(4, st)); hptk_extend_analytic(st, ablocks, s->ds, ps, depth, counters); CHK(ev.end(st)); }      // (fused: k_raygen / k_shade of depth - 1 did it)
-            if (s->ds.n_mesh_instances > 0) { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
+            if (s->ds.n_mesh_instances > 0) {
+                // (timed with the analytic stage: seconds_analytic = everything between the rays and the traversal)
+                if (ps.mq_bin && depth >= 1) { CHK(ev.begin(4, st)); hptk_mq_bin(st, ablocks, s->ds, ps, depth); CHK(ev.end(st)); }
+                CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st));
+            }
         } else { CHK(ev.begin(1, st)); hptk_extend(st, blocks, s->plan, s->ds, ps, depth, counters); CHK(ev.end(st)); }
         CHK(ev.begin(2, st)); hptk_shade(st, sblocks, s->plan, s->ds, ps, depth, s->n_xf, s->n_mat, fused, counters, (ps.flags & HPT_RENDER_EXACT_SHADE) != 0); CHK(ev.end(st));
     }
@@ -950,6 +954,9 @@ static int ensure_pass_workspace(hpt_scene* s, uint64_t n_paths, DPass& ps, int 
     CHK(hit.ensure(hit_sets * max_paths * 16)); CHK(hit_inst.ensure(hit_sets * max_paths * 4)); CHK(radiance.ensure(max_paths * 16));
     ps.hit_par = s->fuse_analytic ? (uint32_t)max_paths : 0u;
     if (!s->ds.use_tlas && s->ds.n_mesh_instances > 0) CHK(mq.ensure(max_paths * 48));      // mesh queue of the instance-list path: items, origins, directions
+    DevBuf& mq_bin = set ? s->x[set - 1].mq_bin : s->w_mq_bin;
+    ps.mq_bin = nullptr;
+    if (hptk_wants_binning(s->ds)) { CHK(mq_bin.ensure(max_paths * 48)); ps.mq_bin = mq_bin.as<uint4>(); }      // big trees: the same queue in cell order
     CHK(counts.ensure((size_t)HPT_COUNTS_TOTAL * sizeof(uint32_t)));
     CHK(s->w_stat.ensure(8 * sizeof(unsigned long long)));
     for (int a = 0; a < 2; ++a) { ps.q[a].ray_o = q[a][0].as<float4>(); ps.q[a].ray_d = q[a][1].as<float4>(); ps.q[a].thr = q[a][2].as<float4>(); }
@@ -1114,7 +1121,7 @@ extern "C" int hpt_render_device_noalloc(hpt_scene* s, const hpt_render_params* 
         ps.q[a].thr = (float4*)(base + HPT_NOALLOC_OFF_Q(3 * a + 2));
     }
     ps.hit = (float4*)(base + HPT_NOALLOC_OFF_HIT); ps.radiance = (float4*)(base + HPT_NOALLOC_OFF_RADIANCE);
-    ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.mq = (uint4*)(base + HPT_NOALLOC_OFF_MQ); ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
+    ps.hit_inst = (uint32_t*)(base + HPT_NOALLOC_OFF_HIT_INST); ps.mq = (uint4*)(base + HPT_NOALLOC_OFF_MQ); ps.mq_bin = nullptr; ps.counts = (uint32_t*)(base + HPT_NOALLOC_OFF_COUNTS);
     ps.stat = (unsigned long long*)(base + HPT_NOALLOC_OFF_STAT);
     ps.hit_par = s->fuse_analytic ? (uint32_t)HPT_NOALLOC_SLOTS : 0u;
     float2* d_halton = (float2*)(base + HPT_NOALLOC_OFF_HALTON);

@@ -41,6 +41,12 @@
 #define HPT_WORK_COUNTER(depth) ((HPT_MAX_DEPTH_LIMIT + 2) * HPT_COUNTS_PER_DEPTH + (depth) * HPT_COUNT_STRIDE)
 #define HPT_MQ_COUNTS(depth) ((HPT_MAX_DEPTH_LIMIT + 2) * (HPT_COUNTS_PER_DEPTH + HPT_COUNT_STRIDE) + (depth) * HPT_COUNTS_PER_DEPTH)
 #define HPT_COUNTS_TOTAL ((HPT_MAX_DEPTH_LIMIT + 2) * (2 * HPT_COUNTS_PER_DEPTH + HPT_COUNT_STRIDE))
+// binned mesh queue (big trees, k_mq_hist / k_mq_scatter): per depth a 64-cell histogram, 64 scatter cursors and the total, in the unused words of the
+// 128-B lines of that depth's mesh-queue append counters (cell c: words 1 and 2 of line c; total: word 3 of line 0)
+#define HPT_MQ_CELLS 64
+#define HPT_MQ_HIST(depth, cell) (HPT_MQ_COUNTS(depth) + (cell) * HPT_COUNT_STRIDE + 1)
+#define HPT_MQ_CURSOR(depth, cell) (HPT_MQ_COUNTS(depth) + (cell) * HPT_COUNT_STRIDE + 2)
+#define HPT_MQ_BINNED_TOTAL(depth) (HPT_MQ_COUNTS(depth) + 3)
 #ifndef HPT_PIECE_BATCH
 #define HPT_PIECE_BATCH 8
 #endif
@@ -164,6 +170,9 @@ struct DPass {
     uint4* mq;           // mesh queue of the current depth, sharded like the path queues: for every ray that entered a mesh box the item
                          // (slot, first mesh instance to visit, best analytic t, its instance | side), then -- HPT_SHARDS * shard_cap records
                          // further on each -- the ray's origin and direction (48 B per slot; see block_analytic)
+    uint4* mq_bin;       // NULL, or a second mesh queue of the same size: scenes with big trees (beyond the L2s) walk the rays of depths >= 1 in the
+                         // order of the 4 x 4 x 4 cell of the first mesh's box their origin lies in (k_mq_hist + k_mq_scatter fill it as ONE linear
+                         // array; its length sits at counts[HPT_MQ_BINNED_TOTAL(depth)])
     float4* radiance;    // (L.rgb, 0) of sample s of slot i at [s * n_slots + i] (k_resolve reads it coalesced); zeroed by the pass
     uint32_t* counts;    // [HPT_MAX_DEPTH_LIMIT+2][HPT_SHARDS] live paths per depth and queue segment, HPT_COUNT_STRIDE apart
     uint32_t shard_cap;  // slots per segment (multiple of HPT_BLOCK); a queue holds HPT_SHARDS * shard_cap slots

@@ -1279,8 +1279,12 @@ k_extend(DScene sc, DPass ps, int depth, int stack_entries, int refill) {
     float4* hit = ps.hit + (size_t)(depth & 1) * ps.hit_par; uint32_t* hit_inst = ps.hit_inst + (size_t)(depth & 1) * ps.hit_par;
     if constexpr (TLAS) block_closest_hit_tlas<COUNT, NODE32, DEFER, true, MESHES, STK16>(sc, L, wv, q.ray_o, q.ray_d, hit, hit_inst, n_int, n_tri, n_inst);
     else {
-        wv.counts = ps.counts + HPT_MQ_COUNTS(depth);      // instance-list path: the input is the mesh queue k_extend_a filled
-        block_closest_hit<COUNT, NODE32, false, DYN, STK16, true>(sc, L, wv, ps.mq, q.ray_o, q.ray_d, hit, hit_inst, n_int, n_tri, n_inst);
+        wv.counts = ps.counts + HPT_MQ_COUNTS(depth);      // instance-list path: the input is the mesh queue the analytic stage filled
+        const void* mq = ps.mq;
+        if (ps.mq_bin && depth >= 1) {                     // ... or its copy in cell order: one linear array (a one-segment queue)
+            wv.counts = ps.counts + HPT_MQ_BINNED_TOTAL(depth); wv.cap = HPT_SHARDS * ps.shard_cap; wv.shards = 1; mq = ps.mq_bin;
+        }
+        block_closest_hit<COUNT, NODE32, false, DYN, STK16, true>(sc, L, wv, mq, q.ray_o, q.ray_d, hit, hit_inst, n_int, n_tri, n_inst);
     }
     if (COUNT) {
         unsigned long long a = wave_sum<unsigned long long>(n_int), b = wave_sum<unsigned long long>(n_tri),
@@ -1303,6 +1307,85 @@ k_extend_a(DScene sc, DPass ps, int depth) {
     if (COUNT) {
         const unsigned long long c = wave_sum<unsigned long long>(n_inst);
         if ((threadIdx.x & 63) == 0) atomicAdd(&ps.stat[3], c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ binned mesh queue
+// Scenes whose trees leave the L2s (1 M-triangle soup: 112 MB of nodes and triangles behind eight 4 MB L2s): after a bounce the queue holds the
+// rays in random order, and every box step of every lane goes to the Infinity Cache / HBM.  The same rays walked in the order of the CELL their
+// origin lies in -- a 4 x 4 x 4 grid over the box of the ray's first mesh, Morton order -- take 0.79 of the time (scripts/gpu_sort_ab.py,
+// profiles/r03f_ray_order_ab.txt: 16 M bounce-like rays; 2^3 cells 0.83, 8^3 0.78, 64^3 + octant 0.71; on the L2-resident teapot 0.95 at best, so
+// small trees keep the queue as it comes).  Built as a variant (hptk_wants_binning below: in the render pipeline it does not pay yet).  Two streaming launches per depth >= 1 (depth 0 holds the camera rays, coherent as they are):
+// k_mq_hist counts the items per cell; k_mq_scatter turns the counts into offsets and copies every 48-B slot (item, origin, direction -- the ray
+// in the space of its first mesh) to its cell's range of DPass.mq_bin, which k_extend then reads as ONE linear queue through the work counter, i.e.
+// cell after cell.  Exact offsets: no segment can overflow whatever the distribution of the origins.  Results do not depend on the order of the
+// items (a ray's result goes to hit[slot]), so the atomics' order inside a cell is free.
+__device__ __forceinline__ uint32_t mq_cell(const DScene& sc, uint32_t item_y, float4 o) {
+    const DMesh& m = sc.meshes[item_y >> 16];
+    const float sx = 4.0f / fmaxf(m.bmax[0] - m.bmin[0], 1.0e-30f), sy = 4.0f / fmaxf(m.bmax[1] - m.bmin[1], 1.0e-30f), sz = 4.0f / fmaxf(m.bmax[2] - m.bmin[2], 1.0e-30f);
+    // (clamped as floats: an origin far outside the box -- or a NaN, which fmaxf drops -- lands in a border cell)
+    const uint32_t cx = (uint32_t)fminf(fmaxf((o.x - m.bmin[0]) * sx, 0.0f), 3.0f), cy = (uint32_t)fminf(fmaxf((o.y - m.bmin[1]) * sy, 0.0f), 3.0f),
+                   cz = (uint32_t)fminf(fmaxf((o.z - m.bmin[2]) * sz, 0.0f), 3.0f);
+    return (cx & 1u) | ((cy & 1u) << 1) | ((cz & 1u) << 2) | ((cx & 2u) << 2) | ((cy & 2u) << 3) | ((cz & 2u) << 4);
+}
+#define HPT_BIN_ROUND 4      // 256-slot chunks a workgroup handles per round of k_mq_scatter: 1 024 items -> runs of ~16 slots per cell
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_mq_hist(DScene sc, DPass ps, int depth) {
+    __shared__ uint32_t h[HPT_MQ_CELLS];
+    if (threadIdx.x < HPT_MQ_CELLS) h[threadIdx.x] = 0u;
+    __syncthreads();
+    WorkView wv; wv.counts = ps.counts + HPT_MQ_COUNTS(depth); wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.work = nullptr;
+    const uint32_t mq_n = HPT_SHARDS * ps.shard_cap;
+    const uint32_t total = input_pieces(wv) / (HPT_BLOCK / 64);
+    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+        uint32_t e;
+        if (work_slot(wv, w, e)) atomicAdd(&h[mq_cell(sc, ps.mq[e].y, ((const float4*)ps.mq)[mq_n + e])], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < HPT_MQ_CELLS && h[threadIdx.x]) atomicAdd(&ps.counts[HPT_MQ_HIST(depth, threadIdx.x)], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(HPT_BLOCK)
+k_mq_scatter(DScene sc, DPass ps, int depth) {
+    __shared__ uint32_t pre[HPT_MQ_CELLS], lc[HPT_MQ_CELLS], base[HPT_MQ_CELLS];
+    if (threadIdx.x < HPT_MQ_CELLS) {      // (the first wave) exclusive prefix of the histogram
+        const uint32_t v = ps.counts[HPT_MQ_HIST(depth, threadIdx.x)];
+        uint32_t incl = v;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, off); if ((int)threadIdx.x >= off) incl += u; }
+        pre[threadIdx.x] = incl - v; lc[threadIdx.x] = 0u;
+        if (blockIdx.x == 0 && threadIdx.x == HPT_MQ_CELLS - 1) ps.counts[HPT_MQ_BINNED_TOTAL(depth)] = incl;
+    }
+    __syncthreads();
+    WorkView wv; wv.counts = ps.counts + HPT_MQ_COUNTS(depth); wv.cap = ps.shard_cap; wv.shards = HPT_SHARDS; wv.n_linear = 0; wv.work = nullptr;
+    const uint32_t mq_n = HPT_SHARDS * ps.shard_cap;
+    const uint32_t total = input_pieces(wv) / (HPT_BLOCK / 64), rounds = (total + HPT_BIN_ROUND - 1) / HPT_BIN_ROUND;
+    const uint4* __restrict__ src = ps.mq; uint4* __restrict__ dst = ps.mq_bin;
+    for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+        uint32_t e[HPT_BIN_ROUND], cell[HPT_BIN_ROUND], rank[HPT_BIN_ROUND]; bool valid[HPT_BIN_ROUND];
+        uint4 item[HPT_BIN_ROUND]; float4 org[HPT_BIN_ROUND];
+#pragma unroll
+        for (int k = 0; k < HPT_BIN_ROUND; ++k) {
+            const uint32_t w = r * HPT_BIN_ROUND + k;
+            valid[k] = w < total && work_slot(wv, w, e[k]);
+            cell[k] = 0u; rank[k] = 0u;
+            if (valid[k]) {
+                item[k] = src[e[k]]; org[k] = ((const float4*)src)[mq_n + e[k]];
+                cell[k] = mq_cell(sc, item[k].y, org[k]);
+                rank[k] = atomicAdd(&lc[cell[k]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < HPT_MQ_CELLS) { const uint32_t c = lc[threadIdx.x]; if (c) base[threadIdx.x] = atomicAdd(&ps.counts[HPT_MQ_CURSOR(depth, threadIdx.x)], c); }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < HPT_BIN_ROUND; ++k) {
+            if (valid[k]) {
+                const uint32_t d = pre[cell[k]] + base[cell[k]] + rank[k];
+                dst[d] = item[k]; ((float4*)dst)[mq_n + d] = org[k]; ((float4*)dst)[2u * mq_n + d] = ((const float4*)src)[2u * mq_n + e[k]];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < HPT_MQ_CELLS) lc[threadIdx.x] = 0u;
+        __syncthreads();
     }
 }
 
@@ -1963,6 +2046,20 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     p.shade_per_cu = p.shade_lds ? resident_blocks(k_shade<true>, p.shade_tables) : resident_blocks(k_shade<false>, 0);
     p.shade_fused_per_cu = p.shade_lds ? resident_blocks(k_shade<true, true, false>, p.shade_tables) : resident_blocks(k_shade<false, true, false>, 0);
     *out = p;
+}
+// mesh queue of `depth` into cell order (DPass.mq_bin): scenes for which hptk_wants_binning() holds, depths >= 1
+// OFF by default: on the 1 M-triangle soup frame the traversal gains 8 % (k_extend 8.35 -> 7.66 ms per launch: the bounce rays of that frame start in
+// the front quarter of the cube, and the deep depths hold too few rays per cell) and the two launches cost 8.7 % of the step -- 2 033 -> 1 959 Mrays/s
+// (profiles/r03f_ray_order_ab.txt).  HPT_MQ_BIN, read per render: 1 = scenes that take the work counter (big trees), 2 = every instance-list scene
+// with meshes (tests), unset / 0 = never.
+bool hptk_wants_binning(const DScene& sc) {
+    const char* e = getenv("HPT_MQ_BIN");
+    const int mode = e ? atoi(e) : 0;
+    return !sc.use_tlas && sc.n_mesh_instances > 0 && (mode == 2 || (mode == 1 && extend_dynamic(sc)));
+}
+void hptk_mq_bin(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth) {
+    hipLaunchKernelGGL(k_mq_hist, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth);
+    hipLaunchKernelGGL(k_mq_scatter, dim3(blocks), dim3(HPT_BLOCK), 0, st, sc, ps, depth);
 }
 static int g_refill = 24;
 void hptk_set_refill(int v) { if (v >= 1 && v <= 64) g_refill = v; }

@@ -19,6 +19,9 @@ struct HptkPlan {          // what hptk_plan derives from a committed scene (see
 void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPlan* out);
 // instance-list scenes: analytic stage of a depth (every ray; fills the mesh queue), then hptk_extend over the mesh queue
 void hptk_extend_analytic(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth, bool count);
+// big trees (hptk_wants_binning): mesh queue of a depth >= 1 copied into cell order (DPass.mq_bin) before hptk_extend walks it
+bool hptk_wants_binning(const DScene& sc);
+void hptk_mq_bin(hipStream_t st, int blocks, const DScene& sc, const DPass& ps, int depth);
 void hptk_extend(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, bool count);
 void hptk_shade(hipStream_t st, int blocks, const HptkPlan& plan, const DScene& sc, const DPass& ps, int depth, int n_xf, int n_mat, bool fuse, bool count, bool exact);
 void hptk_halton(hipStream_t st, float2* out, uint32_t first_sample, uint32_t n);      // out[k] = halton(first_sample + k + 1, 2 | 3)

@@ -71,7 +71,8 @@ def frame_properties(ctx, desc, spp, depth):
         sc.close(); sc2.close()
 
 
-def test_config3_soup_1m_triangles(ctx, olib):
+def test_config3_soup_1m_triangles(ctx, olib, monkeypatch):
+    import torch
     import hpt
     desc = scenes.soup(1_000_000, w=1920, h=1080)
     gsc = hpt.Scene(ctx, desc)                               # bvh.rs degenerates on unordered input: the library builds the tree
@@ -79,6 +80,16 @@ def test_config3_soup_1m_triangles(ctx, olib):
     assert info.n_triangles == 1_000_000 and info.n_nodes == 999_999 and info.node_bytes == 32 and info.uses_tlas == 0
     n = hits_against_oracle(gsc, ol.OracleScene(olib, desc), desc, 3000, 5)      # 1 500 camera rays + the bounce rays of their hits
     assert n > 2000
+    # the variant that walks the mesh queue in cell order (HPT_MQ_BIN=1 -> DPass.mq_bin): the frame keeps its bits
+    npix = 1920 * 1080
+    a, b = (torch.zeros((npix, 4), dtype=torch.int64, device="cuda") for _ in range(2))
+    torch.cuda.synchronize()
+    st_a = gsc.render_accum_device(a.data_ptr(), 0, 0, npix, want_stats=True, spp=2, max_depth=8, seed=9)
+    monkeypatch.setenv("HPT_MQ_BIN", "1")
+    st_b = gsc.render_accum_device(b.data_ptr(), 0, 0, npix, want_stats=True, spp=2, max_depth=8, seed=9)
+    monkeypatch.delenv("HPT_MQ_BIN")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and (st_a.rays_bounce, st_a.rays_mesh) == (st_b.rays_bounce, st_b.rays_mesh) and st_a.rays_mesh > 0
     gsc.close()
     frame_properties(ctx, desc, spp=4, depth=8)
 

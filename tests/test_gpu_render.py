@@ -380,3 +380,34 @@ def test_fused_analytic_stage_equals_separate_kernels(ctx, desc, monkeypatch):
         assert a[2] == b[2] and a[3] == b[3]
     rays = res[0][0][2][0] + res[0][0][2][1]
     assert int(res[0][0][0][:, :3].sum()) > 0 and 8 * rays <= res[0][0][2][2] <= 9 * rays      # every ray met the eight analytic instances (+ the mesh box)
+
+
+def test_binned_mesh_queue_changes_no_result(ctx, desc, monkeypatch):
+    """big trees walk the mesh queue of depths >= 1 in the order of the cell the ray starts in (k_mq_hist + k_mq_scatter -> DPass.mq_bin, one
+    linear queue): the same rays, so accumulators, per-pixel min/max and ray counts keep their bits -- forced on here for a small scene
+    (HPT_MQ_BIN=2) against off (0), in both shade modes, with ragged passes, a pixel list and the separate analytic kernels too."""
+    import torch
+    import hpt
+    d = resized(desc, 80, 60)
+    npix = 80 * 60
+    plist = torch.arange(1, npix, 3, dtype=torch.int32, device="cuda")
+    res = []
+    for fuse, binned in (("1", "0"), ("1", "2"), ("0", "2")):
+        monkeypatch.setenv("HPT_FUSE_ANALYTIC", fuse); monkeypatch.setenv("HPT_MQ_BIN", binned)
+        sc = hpt.Scene(ctx, d, host_bvh=host_tree)
+        got = []
+        for flags in (0, hpt.RENDER_EXACT_SHADE):
+            acc = torch.zeros((npix, 4), dtype=torch.int64, device="cuda")
+            mm = torch.empty((npix, 6), dtype=torch.float32, device="cuda"); mm[:, :3] = float("inf"); mm[:, 3:] = 0.0
+            torch.cuda.synchronize()
+            st = sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), 0, npix, want_stats=True, spp=7, max_depth=8, seed=5, spp_per_pass=3, flags=flags)
+            st2 = sc.render_accum_device(acc.data_ptr(), mm.data_ptr(), plist.data_ptr(), len(plist), want_stats=True, spp=2, first_sample=7, max_depth=4, seed=5, flags=flags)
+            torch.cuda.synchronize()
+            got.append((acc.cpu().numpy(), mm.cpu().numpy(), (st.rays_primary, st.rays_bounce, st.rays_mesh), (st2.rays_primary, st2.rays_bounce, st2.rays_mesh)))
+        res.append(got)
+        sc.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+            assert a[2] == b[2] and a[3] == b[3]
+    assert int(res[0][0][0][:, :3].sum()) > 0 and res[0][0][2][2] > 0
