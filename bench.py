@@ -16,11 +16,12 @@ Inputs are resident in HBM before the timed region (the scene is committed once)
   python bench.py --config soup|instanced|spheres ...     the other BASELINE.json configs at full size as a line of their own
 
 The default N=1 run also carries "other_configs": configs[2] (1 M-triangle soup, 256 spp) and configs[4] (10 k spheres, 256 spp,
-depth 16) at their BASELINE sizes, one step each after the headline (--no-others skips them).
+depth 16) at their BASELINE sizes and configs[3] (3 375 instanced teapots at 4K) with 512 spp -- one GPU's share of the 4096 spp that
+config splits over 8 GPUs --, one step each after the headline (--no-others skips them).
 
 Extra objects on the JSON line: "roofline" (k_extend, the BVH traversal kernel: algorithmic bytes / HIP-event kernel time vs the
-8 TB/s HBM peak.  The analytic stage of the extend step -- spheres, planes, mesh root boxes -- runs inside k_shade on the ray that
-kernel has just made, k_extend_a only at depth 0: analytic_share_of_step is that depth-0 launch, shade_share_of_step covers the rest;
+8 TB/s HBM peak.  The analytic stage of the extend step -- spheres, planes, mesh root boxes -- runs inside the kernel that has just made
+the ray (k_raygen at depth 0, k_shade later): analytic_share_of_step is 0 unless HPT_FUSE_ANALYTIC=0, shade_share_of_step covers the stage;
 the event-bracketed launches are the same K steps run once more on ONE stream, right after the timed region: with two
 passes in flight the event interval of a launch would also cover the other pass's kernels sharing the GPU with it;
 `hbm_physical` / `valu` = the committed rocprofv3 counter passes of the same frame, flagged `stale` when they were
@@ -343,11 +344,12 @@ def measure(args, scene, desc, tree, workload, base, world, rank, backend, strea
     return line
 
 
-def other_config_line(name, ctx, stream):
+def other_config_line(name, ctx, stream, spp=0):
     """One step of another BASELINE.json config at its full size, for the driver's default line: throughput, the traversal
-    kernel's launch time and visits per ray, the committed counter figures of that config."""
+    kernel's launch time and visits per ray, the committed counter figures of that config.  spp: samples of the step when it is not the
+    config's whole frame (instanced: 512 = one GPU's share of the 4096 spp the config splits over 8 GPUs)."""
     import copy
-    a = argparse.Namespace(config=name, width=CONFIGS[name][1], height=CONFIGS[name][2], spp=CONFIGS[name][3], depth=CONFIGS[name][4],
+    a = argparse.Namespace(config=name, width=CONFIGS[name][1], height=CONFIGS[name][2], spp=spp or CONFIGS[name][3], depth=CONFIGS[name][4],
                            spp_per_pass=0, steps=1, warmup=0, tree="host", inflight=0)
     t0 = time.perf_counter()
     desc, tree, workload = build_workload(a)
@@ -380,7 +382,7 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--cpu-spp", type=int, default=-1, help="samples per pixel of the CPU-baseline sample (0 = skip; default 12 for the teapot frame, 0 else)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra measurement with the handed-over tree left as it came")
-    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs (soup, spheres) the default N=1 teapot run appends as other_configs")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs (soup, instanced teapots, spheres) the default N=1 teapot run appends as other_configs")
     ap.add_argument("--tree", choices=["host", "sah"], default="host", help="host: reference bvh.rs tree handed over (drop-in); sah: library-built")
     ap.add_argument("--inflight", type=int, default=0, help="wavefront passes in flight (0 = library default, 2; 1 = one stream: every launch has the GPU to itself, "
                     "the setting of the rocprofv3 kernel-trace runs)")
@@ -458,7 +460,7 @@ def main():
     if rank == 0:
         if world == 1 and full_default and not args.no_others:
             # the other single-GPU BASELINE configs at their full sizes, one step each: driver-visible
-            line["other_configs"] = {name: other_config_line(name, ctx, stream) for name in ("soup", "spheres")}
+            line["other_configs"] = {name: other_config_line(name, ctx, stream, spp) for name, spp in (("soup", 0), ("instanced", 512), ("spheres", 0))}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
