@@ -25,7 +25,8 @@ the ray (k_raygen at depth 0, k_shade later): analytic_share_of_step is 0 unless
 the event-bracketed launches are the same K steps run once more on ONE stream, right after the timed region: with two
 passes in flight the event interval of a launch would also cover the other pass's kernels sharing the GPU with it;
 `hbm_physical` / `valu` = the committed rocprofv3 counter passes of the same frame, flagged `stale` when they were
-taken with other kernel sources than the tree holds; `limiter` = which of the two is closer to its peak)
+taken with other kernel sources than the tree holds; `limiter` = which of the two is closer to its peak; `shade_stage` = the same figures
+for k_shade, the largest kernel of the step since round 3: HIP-event launch time, algorithmic and physical bytes, VALU counters)
 and "cpu_baseline" (the C restatement of the reference -- oracle/liboracle_fast.so -- on the host cores, rank 0, N=1).
 """
 import argparse
@@ -301,7 +302,14 @@ def measure(args, scene, desc, tree, workload, base, world, rank, backend, strea
     survive = (rays_local - sum(s.rays_primary for s in stats)) / rays_local
     shade_bytes_per_ray = 68.0 + survive * (48.0 + (20.0 + 48.0 * walked_frac if not info.uses_tlas else 0.0))
     shade_valu = recorded_valu("k_shade", args.config) if default_frame else None
-    shade_stage = {"kernel": "k_shade" + ("" if info.uses_tlas else " (+ analytic stage of the next depth)"),
+    shade_traffic = recorded_traffic("k_shade", args.config) if default_frame else None
+    shade_physical = None
+    if shade_traffic and shade_traffic.get("rays_per_launch") and shade_s_local:
+        sb = shade_traffic["bytes_per_launch"] / shade_traffic["rays_per_launch"] * rays_per_launch      # scaled per ray like k_extend's
+        ss = shade_s_local / max(ext_launches, 1)
+        shade_physical = {"bytes_per_launch": int(sb), "GB/s": round(sb / ss / 1e9, 1), "frac": round(sb / ss / HBM_PEAK, 4),
+                          "bytes_per_ray": round(sb / rays_per_launch, 1), "source": shade_traffic["source"], "stale": shade_traffic["stale"]}
+    shade_stage = {"kernel": "k_shade" + ("" if info.uses_tlas else " (+ analytic stage of the next depth)"), "bound": "hbm", "hbm_physical": shade_physical,
                    "avg_launch_ms": round(shade_s_local / max(ext_launches, 1) * 1e3, 4), "bytes_per_ray": round(shade_bytes_per_ray, 1),
                    "GB/s": round(shade_bytes_per_ray * rays_local / shade_s_local / 1e9, 1) if shade_s_local else None,
                    "frac": round(shade_bytes_per_ray * rays_local / shade_s_local / HBM_PEAK, 4) if shade_s_local else None,
