@@ -896,7 +896,10 @@ static int extend_grid(const hpt_scene* s, int inflight) {
         //  2 / 3 / 4 / 5 per CU of 5 resident = 2.86 / 3.17 / 3.21 / 3.11 Grays/s, 10 k spheres 2 / 3 / 4 of 4 = 4.19 / 4.27 / 4.15)
         // (instance-list path: every resident slot since k_shade carries the analytic stage -- r03e, 1080p teapot, two passes in flight:
         //  4 / 6 / 7 of 7 per CU = 17.97 / 18.45 / 18.49 Grays/s; r03b, with the analytic stage a kernel of its own, had 4 ahead; the soup does not care)
-        const int spare = ctx->extend_spare >= 0 ? ctx->extend_spare : (s->ds.use_tlas ? 1 : 0);
+        // (instance-list path with a big tree -- the 1 M-triangle soup, bandwidth-bound, fed through the work counter: HALF the resident slots, so that
+        //  the traversals of both passes in flight are resident side by side -- r03f, 4 resident: 1 / 2 / 3 / 4 per CU = 1.63 / 2.14 / 2.12 / 2.04 Grays/s,
+        //  while on one stream the kernel itself saturates at 4: 19.8 / 11.0 / 8.7 / 8.3 ms per launch)
+        const int spare = ctx->extend_spare >= 0 ? ctx->extend_spare : (s->ds.use_tlas ? 1 : (s->plan.extend_counter ? per_cu / 2 : 0));
         if (inflight > 1 && per_cu > spare) per_cu -= spare;
     }
     return ctx->num_cus * std::max(1, per_cu);

@@ -2037,6 +2037,7 @@ void hptk_plan(int stack_entries, const DScene& sc, int n_xf, int n_mat, HptkPla
     p.extend_mode = scene_lds_mode(p.extend_entries, sc);
     p.extend_lds = trav_lds_bytes(p.extend_entries, p.extend_mode, extend_stk16(sc) || tlas_stk16(sc), tlas_meshes(sc));
     p.extend_per_cu = extend_resident(sc, p.extend_mode == LDS_TLAS, p.extend_lds);
+    p.extend_counter = sc.use_tlas || extend_dynamic(sc);
     p.analytic_per_cu = resident_blocks(k_extend_a<false>, 0);
     p.shade_tables = (size_t)sc.n_instances * sizeof(DInstance) + (size_t)n_xf * (sizeof(DXformInv) + sizeof(DXformFwd)) + (size_t)n_mat * sizeof(DMaterial) +
                      (size_t)sc.n_instances * sizeof(float4);

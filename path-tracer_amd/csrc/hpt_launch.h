@@ -13,6 +13,7 @@ void hptk_raygen(hipStream_t st, int max_blocks, const DScene& sc, const DPass& 
 struct HptkPlan {          // what hptk_plan derives from a committed scene (see hpt_kernels.hip)
     int extend_entries = 1, extend_mode = 0, extend_per_cu = 0;   // stack entries carved, LDS layout, resident workgroups per CU (0: query failed)
     size_t extend_lds = 0;
+    bool extend_counter = false;                                  // the traversal kernel takes its input through the work counter (two-level scenes, big trees)
     int analytic_per_cu = 0;                                      // resident workgroups per CU of k_extend_a
     size_t shade_tables = 0; bool shade_lds = false; int shade_per_cu = 0, shade_fused_per_cu = 0;   // (fused: k_shade + the next depth's analytic stage)
 };
