@@ -464,7 +464,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         }
         if (!flatten_mesh(*use, m.verts.data(), m.tri.data(), m.normals.data(), m.ntri.data(), m.uvw.data(), m.ttri.data(), m.n_tri, fm, err))
             return fail(HPT_ERR_INVALID, "%s", err.c_str());
-        const int64_t node_base = (int64_t)(nodes.size() / 16), tri_base = (int64_t)(tris.size() / 12);
+        const int64_t node_base = (int64_t)(nodes.size() / 16), tri_base = (int64_t)(tris.size() / HPT_TRI_FLOATS);
         if (node_base + fm.n_interior >= (1ll << 31) || tri_base + m.n_tri >= (1ll << 31)) return fail(HPT_ERR_LIMIT, "scene: more than 2^31 nodes/triangles");
         auto rebase = [&](int32_t ref) -> int32_t { return ref >= 0 ? (int32_t)(ref + node_base) : ~(int32_t)((~ref) + tri_base); };
         for (int32_t i = 0; i < fm.n_interior; ++i) {
@@ -536,7 +536,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         }
     }
     if (inst.size() >= 0x3fffffffu) return fail(HPT_ERR_LIMIT, "too many instances");
-    if (tris.size() / 12 >= 0x40000000ull) return fail(HPT_ERR_LIMIT, "scene: more than 2^30 triangles");
+    if (tris.size() / HPT_TRI_FLOATS >= 0x40000000ull) return fail(HPT_ERR_LIMIT, "scene: more than 2^30 triangles");
     // ---- TLAS over the instances' world boxes when the linear instance loop of scene.rs:193 would dominate
     int tlas_min = 24;
     if (const char* e = getenv("HPT_TLAS_MIN")) tlas_min = atoi(e);
@@ -589,7 +589,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
         // leaf refs: ~(inst_base + i) for a mesh instance, ~(analytic_base + i) for a sphere / plane (the kernel may defer those);
         // codes packed from 0 when they and the interior refs fit a signed 16-bit stack entry (hpt_device.h DScene.inst_base)
         if (inst.size() >= (1u << 26)) return fail(HPT_ERR_LIMIT, "scene: more than 2^26 instances");
-        const uint64_t n_tri_all = tris.size() / 12, n_codes = n_tri_all + 2 * (uint64_t)inst.size() + 1;
+        const uint64_t n_tri_all = tris.size() / HPT_TRI_FLOATS, n_codes = n_tri_all + 2 * (uint64_t)inst.size() + 1;
         // ... for the scenes whose traversal tests everything in place (analytic instances below a quarter, triangle deferral off):
         // that kernel variant then runs with a 16-bit stack at five waves per SIMD; the deferring variants are register-bound at four
         size_t n_analytic = 0;
@@ -684,7 +684,7 @@ extern "C" int hpt_scene_commit(hpt_scene* s) {
     d.materials = s->d_materials.as<DMaterial>(); d.images = s->d_images.as<DImage>(); d.image_pool = s->d_pool.as<uint8_t>();
     d.n_instances = (int32_t)inst.size(); d.n_meshes = (int32_t)s->h_meshes.size();
     s->n_xf = (int)xinv.size(); s->n_mat = (int)mats.size();
-    s->n_tris_total = (int64_t)(tris.size() / 12);
+    s->n_tris_total = (int64_t)(tris.size() / HPT_TRI_FLOATS);
     s->device_bytes = (node32 ? nodes32.size() : nodes.size()) * 4 + tris.size() * 4 + trishade.size() * 4 + inst.size() * sizeof(DInstance) + xinv.size() * sizeof(DXformInv) +
                       xfwd.size() * sizeof(DXformFwd) + mats.size() * sizeof(DMaterial) + pool.size();
     d.use_tlas = use_tlas; d.tlas_root = tlas_root;

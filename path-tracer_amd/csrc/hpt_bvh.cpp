@@ -444,13 +444,13 @@ bool flatten_mesh(const HostTree& tree, const float* verts, const uint32_t* tri_
         for (int k = 0; k < 3; ++k) { leaf[6 * (size_t)f + k] = x.mn[k]; leaf[6 * (size_t)f + 3 + k] = x.mx[k]; }
     }
     if (!flatten_tree(tree, leaf.data(), ntri, out, err)) return false;
-    out.tris.assign((size_t)ntri * 12, 0.0f);
+    out.tris.assign((size_t)ntri * HPT_TRI_FLOATS, 0.0f);
     out.trishade.assign((size_t)ntri * 28, 0.0f);
     for (int32_t f = 0; f < ntri; ++f) {
         const float* a = verts + 3 * (size_t)tri_idx[3 * (size_t)f];
         const float* b = verts + 3 * (size_t)tri_idx[3 * (size_t)f + 1];
         const float* c = verts + 3 * (size_t)tri_idx[3 * (size_t)f + 2];
-        float* t = &out.tris[(size_t)f * 12];
+        float* t = &out.tris[(size_t)f * HPT_TRI_FLOATS];
         for (int k = 0; k < 3; ++k) { t[k] = a[k]; t[4 + k] = b[k] - a[k]; t[8 + k] = c[k] - a[k]; }   // geometry.rs:189-190
         float* s = &out.trishade[(size_t)f * 28];
         for (int k = 0; k < 3; ++k) { s[k] = a[k]; s[3 + k] = b[k]; s[6 + k] = c[k]; }

@@ -5,6 +5,12 @@
 #include <string>
 #include <vector>
 #include "../../include/hpt.h"
+#ifndef HPT_TRI_QUADS
+#define HPT_TRI_QUADS 4          // 16-B quads per triangle record: see hpt_device.h
+#endif
+#ifndef HPT_TRI_FLOATS
+#define HPT_TRI_FLOATS (HPT_TRI_QUADS * 4)
+#endif
 
 struct HostTree {           // binary tree over primitives, one primitive per leaf (bvh.rs:49-55)
     std::vector<int32_t> left, right, prim;   // interior: left/right >= 0, prim = -1; leaf: prim >= 0
@@ -13,7 +19,7 @@ struct HostTree {           // binary tree over primitives, one primitive per le
 
 struct FlatMesh {
     std::vector<float> nodes;      // n_interior * 16 floats (Node64)
-    std::vector<float> tris;       // ntri * 12 floats (Tri48)
+    std::vector<float> tris;       // ntri * HPT_TRI_FLOATS floats (Tri48)
     std::vector<float> trishade;   // ntri * 28 floats (TriShade)
     int32_t root_ref = -1;         // LOCAL ref: >= 0 interior index, < 0 ~local triangle
     int32_t n_interior = 0;

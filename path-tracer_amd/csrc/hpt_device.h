@@ -22,7 +22,13 @@
 #define HPT_BLOCK 256          // threads per workgroup: 4 wave64 (128 and 512 measured slower)
 #endif
 #define HPT_NODE_QUADS 4
-#define HPT_TRI_QUADS 3
+#ifndef HPT_TRI_QUADS
+#define HPT_TRI_QUADS 4          // 16-B quads per triangle record: (a, b - a, c - a) = 48 B, padded to 64 B so that no record straddles a 128-B line
+                                 // (one in four 48-B records does; r03g A/B of 3 vs 4: soup +1.3 %, k_extend -1.6 %; teapot, instanced teapots +-0)
+#endif
+#ifndef HPT_TRI_FLOATS
+#define HPT_TRI_FLOATS (HPT_TRI_QUADS * 4)
+#endif
 #define HPT_TRISHADE_QUADS 7
 #define HPT_MISS_INST 0x7fffffffu
 #define HPT_MAX_DEPTH_LIMIT 64   // max bounces (size of the per-depth live-count array)
